@@ -1,0 +1,251 @@
+/*
+ * libmtam_hip.so -- C ABI of the MI355X (gfx950) time-aware training path.
+ *
+ * The reference (cocoandpudding/MTAMRecommender) has no FFI: its hot path is a
+ * TensorFlow 1.14 graph run by sess.run (Model/base_model.py:159-164 train,
+ * :201-202 eval).  Each entry point below replaces a group of graph ops; the
+ * comment on each names the reference lines.  A maintainer binds them with
+ * ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative MTAM_E_* code otherwise;
+ *     mtam_last_error() gives a thread-local message;
+ *   - every pointer is a DEVICE pointer unless named host_*; the library never
+ *     allocates, frees or keeps caller memory; scratch is passed in;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and is
+ *     asynchronous; calls are re-entrant across streams and safe to capture
+ *     into a hipGraph (no allocation, no synchronisation inside);
+ *   - matrices are row-major contiguous float32 unless a leading dimension is
+ *     given; ids and lengths are int32; times are float32 (raw hours);
+ *   - D (num_units) must be 128 in this build (MTAM_D).
+ */
+#ifndef MTAM_HIP_H
+#define MTAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTAM_D 128
+
+#define MTAM_OK 0
+#define MTAM_E_ARG (-1)     /* bad argument (shape, alignment, null pointer) */
+#define MTAM_E_LAUNCH (-2)  /* hipLaunch failure */
+#define MTAM_E_UNSUPPORTED (-3)
+
+const char *mtam_last_error(void);
+int mtam_version(void);          /* 1000*major + minor */
+const char *mtam_arch(void);     /* "gfx950" */
+
+/* ------------------------------------------------------------------ GEMM
+ * C[M,N] = op(A) * op(B) with a fused epilogue; fp32 in, fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain per output element).
+ * Replaces tf.layers.dense / tf.matmul on the path
+ * (Embedding/Behavior_embedding_time_aware_attention.py:95-103,
+ *  Model/Modules/time_aware_attention.py:249-253, Model/base_model.py:316)
+ * and their tf.gradients counterparts (Model/base_model.py:292).
+ *   trans_a == 0: A is [M,K] (lda >= K);  trans_a == 1: A is [K,M] (lda >= M)
+ *   trans_b == 0: B is [K,N] (ldb >= N);  trans_b == 1: B is [N,K] (ldb >= K)
+ * Epilogues (acc = the product):
+ *   MTAM_EPI_STORE       C = acc
+ *   MTAM_EPI_BIAS        C = acc + bias[n]
+ *   MTAM_EPI_BIAS_RELU   C = relu(acc + bias[n])
+ *   MTAM_EPI_RELU_ADD    aux_out = relu(acc); C = relu(acc) + aux_in[m,n]
+ *   MTAM_EPI_ACCUM       C += acc
+ *   MTAM_EPI_ACCUM_MASK  C += acc; aux_out = (aux_in[m,n] > 0) ? C : 0
+ *   MTAM_EPI_ATOMIC      atomicAdd(C, acc)   (split_k >= 1 slices of K)
+ * aux_in / aux_out share ld_aux.  split_k > 1 is only valid with ATOMIC.
+ */
+enum {
+  MTAM_EPI_STORE = 0,
+  MTAM_EPI_BIAS = 1,
+  MTAM_EPI_BIAS_RELU = 2,
+  MTAM_EPI_RELU_ADD = 3,
+  MTAM_EPI_ACCUM = 4,
+  MTAM_EPI_ACCUM_MASK = 5,
+  MTAM_EPI_ATOMIC = 6
+};
+int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
+                  const float *A, int lda, const float *B, int ldb,
+                  float *C, int ldc, int epilogue, const float *bias,
+                  const float *aux_in, float *aux_out, int ld_aux,
+                  int split_k, void *stream);
+
+/* column sums: out[c] += sum_r in[r, c]  (atomicAdd; bias gradients) */
+int mtam_colsum_atomic(const float *in, int rows, int cols, int ld, float *out, void *stream);
+
+/* --------------------------------------------------------- embedding gather
+ * tf.nn.embedding_lookup x4 (Embedding/Behavior_embedding_time_aware_attention.py:68,75,82,90)
+ * + the concat of :95 + the four tf.nn.l2_loss terms of Model/base_model.py:302-307.
+ *   item_cat_out [B*L, 2D]: row r = [item_table[item_ids[r]] | cat_table[cat_ids[r]]]
+ *   pos_out      [B*L, D],  user_out [B, D]
+ *   l2_partial   [mtam_emb_gather_partials(B, L)] floats: per-wave sums of x^2
+ *                (0.5 * their sum = l2_norm; with_user == 0 leaves the user
+ *                rows out, as Model/PISTRec_model.py:56-60 does).
+ * Ids are clamped into [0, rows) so a bad id cannot fault; validate on the host.
+ */
+int mtam_emb_gather_partials(int B, int L);
+int mtam_emb_gather_fwd(const float *item_table, int item_rows,
+                        const float *cat_table, int cat_rows,
+                        const float *pos_table, int pos_rows,
+                        const float *user_table, int user_rows,
+                        const int32_t *item_ids, const int32_t *cat_ids,
+                        const int32_t *pos_ids, const int32_t *user_ids,
+                        int B, int L, int with_user,
+                        float *item_cat_out, float *pos_out, float *user_out,
+                        float *l2_partial, void *stream);
+
+/* ---------------------------------------------------- embedding scatter-add
+ * Gradient of the four lookups (tf.gradients through embedding_lookup,
+ * Model/base_model.py:292) including the L2 term: slot r contributes
+ * (d_slot[r] + reg * gathered[r]) to row ids[r] of the table's gradient, by
+ * wave-level float atomics (two 128-B row segments per wave instruction).
+ * Padded slots (t >= seq_len[b]) carry d_slot == 0 exactly, so they are not
+ * scattered one by one: their sum, n_pad * reg * row0, is added once.
+ *   d_item_cat [B*L, 2D], d_pos [B*L, D]  upstream gradients
+ *   item_cat   [B*L, 2D], pos [B*L, D], user [B, D]  the gathered rows
+ *   g_item (already holding the dense scoring gradient), g_cat, g_pos, g_user
+ *   slot_sq_partial [mtam_emb_scatter_partials(B, L)]: per-wave sums of
+ *     ||contribution||^2 over un-deduplicated slots (TF IndexedSlices norm,
+ *     SURVEY.md App D-5), pads included.
+ * with_user == 0: the user table gets no gradient (PISTRec).
+ */
+int mtam_emb_scatter_partials(int B, int L);
+int mtam_emb_scatter_add_bwd(const float *d_item_cat, const float *d_pos,
+                             const float *item_cat, const float *pos, const float *user,
+                             const int32_t *item_ids, const int32_t *cat_ids,
+                             const int32_t *pos_ids, const int32_t *user_ids,
+                             const int32_t *seq_len, int B, int L, float reg, int with_user,
+                             float *g_item, int item_rows, float *g_cat, int cat_rows,
+                             float *g_pos, int pos_rows, float *g_user, int user_rows,
+                             float *slot_sq_partial, void *stream);
+
+/* ----------------------------------------------------------- time-aware GRU
+ * dynamic_rnn(TimeAwareGRUCell_decay_new) + gather_indexes(seq_len - 2):
+ * Model/Modules/gru.py:69-77, Model/Modules/time_aware_rnn.py:186-269,
+ * Model/Modules/net_utils.py:82-92, Model/MTAMRec_model.py:68-79.
+ * One workgroup per sample; the recurrent weights live in registers.
+ *   xproj   [B*L, 3D] = x @ [Wg_x | Wc_x] + [bg | bc]   (hoisted input projection)
+ *   x       [B*L, D], timelast [B*L], seq_len [B] (steps = seq_len - 1)
+ *   wh_g    [D, 2D], wh_c [D, D]      recurrent halves of gates/candidate kernels
+ *   tvec    [8, D]: _time_kernel_w1, _time_kernel_b1, _time_history_w1, _time_w1,
+ *                   _time_b1, _time_kernel_w2, _time_w12, _time_b12
+ *   hs      [B*L, D] outputs (zero for t >= seq_len-1), short_out [B, D]
+ *   save    [B*L, 5D] or NULL: per step r | u | c | T | h_prev   (for backward)
+ */
+int mtam_tagru_fwd(const float *xproj, const float *x, const float *timelast,
+                   const int32_t *seq_len, const float *wh_g, const float *wh_c,
+                   const float *tvec, int B, int L,
+                   float *hs, float *short_out, float *save, void *stream);
+
+/* Backward through time of the above.
+ *   d_short [B, D]  gradient of short_out
+ *   d_xproj [B*L, 3D] out: d(gate pre-act) | d(candidate pre-act), zero for dead steps
+ *   rh      [B*L, D] out: r * h_prev (A operand of the candidate-kernel gradient)
+ *   d_x     [B*L, D] in/out: += the time-gate path (dtw * _time_kernel_w1)
+ *   d_tvec_partial [B, 8, D] out: per-sample gradients of tvec (caller column-sums)
+ */
+int mtam_tagru_bwd(const float *d_short, const float *x, const float *timelast,
+                   const int32_t *seq_len, const float *wh_g, const float *wh_c,
+                   const float *tvec, const float *save, int B, int L,
+                   float *d_xproj, float *rh, float *d_x, float *d_tvec_partial,
+                   void *stream);
+
+/* ------------------------------------------ time-aware attention, T_q = 1
+ * One decoder block of vanilla_attention: Model/Modules/time_aware_attention.py:215-456
+ * with t_querys_length = 1 (Model/MTAMRec_model.py:83-90), including the
+ * residual and normalize() (eps 1e-8, :7-34).  One workgroup per sample.
+ *   dec_in [B, D] query;  x [B*L, D] raw keys;  kv [B*L, ld_kv] with K at
+ *   column k_off and V at column v_off (= relu(x @ Wk + bk), relu(x @ Wv + bv))
+ *   t_query [B] target time, t_keys [B*L], seq_len [B] (key_length)
+ *   wqt [D, 2D] = [dense/kernel | _time_input_w],  bq [D]
+ *   tparams [5, L]: _time_input_w1, _time_input_b1, time_output_w1, time_output_w2, time_output_b
+ *   ln_beta, ln_gamma [D]
+ *   dec_out [B, D]
+ *   save [B, mtam_ta_attn_decode_save_floats(L, H)] or NULL
+ */
+int mtam_ta_attn_decode_save_floats(int L, int H);
+int mtam_ta_attn_decode_fwd(const float *dec_in, const float *x, const float *kv, int ld_kv,
+                            int k_off, int v_off, const float *t_query, const float *t_keys,
+                            const int32_t *seq_len, const float *wqt, const float *bq,
+                            const float *tparams, const float *ln_beta, const float *ln_gamma,
+                            int B, int L, int H, float *dec_out, float *save, void *stream);
+
+/*   d_out [B, D] gradient of dec_out
+ *   d_dec_in [B, D] out;  d_kv [B*L, ld_kv] out at k_off / v_off (pre-activation
+ *   gradients, relu mask applied);  d_x [B*L, D]: = or += (accumulate_dx) the
+ *   raw-key path;  d_qt_pre [B, 2D] out: d(Q pre-act) | d(q @ Wt)
+ *   d_tparams_partial [B, 5, L], d_ln_partial [B, 2, D] (beta | gamma): per sample
+ */
+int mtam_ta_attn_decode_bwd(const float *d_out, const float *dec_in, const float *x,
+                            const float *kv, int ld_kv, int k_off, int v_off,
+                            const float *t_query, const float *t_keys, const int32_t *seq_len,
+                            const float *wqt, const float *tparams, const float *ln_gamma,
+                            const float *save, int B, int L, int H, int accumulate_dx,
+                            float *d_dec_in, float *d_kv, float *d_x, float *d_qt_pre,
+                            float *d_tparams_partial, float *d_ln_partial, void *stream);
+
+/* ------------------------------------------------------------- layer norm
+ * tf.contrib.layers.layer_norm (Model/Modules/net_utils.py:229-232,
+ * Model/MTAMRec_model.py:91): y = x*inv + (beta - mean*inv), inv = rsqrt(var+eps)*gamma.
+ *   save [rows, D + 1]: xhat | rstd, or NULL
+ */
+int mtam_layer_norm_fwd(const float *x, const float *beta, const float *gamma, float eps,
+                        int rows, float *y, float *save, void *stream);
+/*   d_bg [2, D]: atomicAdd of d_beta | d_gamma */
+int mtam_layer_norm_bwd(const float *d_y, const float *gamma, const float *save, int rows,
+                        float *d_x, float *d_bg, void *stream);
+
+/* --------------------------------------------------- full-catalog softmax CE
+ * log_softmax + one-hot cross entropy over logits [B, V]
+ * (Model/base_model.py:316-322).  Two launches inside:
+ *   lse[b], ce[b] = lse[b] - logits[b, target[b]]
+ *   if d_logits != NULL: d_logits[b, v] = (exp(logits - lse) - [v == target]) * grad_scale
+ *   (d_logits may alias logits).  grad_scale = 1 / global batch.
+ *   partial: scratch of mtam_softmax_ce_partials(B, V) floats.
+ */
+int mtam_softmax_ce_partials(int B, int V);
+int mtam_softmax_ce(const float *logits, int ld, const int32_t *target, int B, int V,
+                    float grad_scale, float *lse, float *ce, float *d_logits,
+                    float *partial, void *stream);
+
+/* loss[0] = reg * 0.5 * sum(l2_partial) + ce_scale * sum(ce);  loss[1] = 0.5*sum(l2_partial);
+ * loss[2] = sum(ce) / B   (Model/base_model.py:322-326) */
+int mtam_loss_reduce(const float *l2_partial, int n_l2, const float *ce, int B, float reg,
+                     float ce_scale, float *loss, void *stream);
+
+/* ------------------------------------------------------------------ top-K
+ * tf.nn.top_k (Model/base_model.py:196-200): for every row the k largest
+ * scores, descending, equal values -> lower index first.  k <= 64.
+ *   idx_out [rows, k] int32; val_out [rows, k] or NULL
+ */
+int mtam_topk(const float *scores, int ld, int rows, int V, int k,
+              int32_t *idx_out, float *val_out, void *stream);
+
+/* ------------------------------------------------ clip_by_global_norm + Adam
+ * tf.clip_by_global_norm + AdamOptimizer.apply_gradients
+ * (Model/base_model.py:75-76,294-296) [TF1.14 semantics, SURVEY.md App D-5/6].
+ *
+ * mtam_sqnorm_partial: partial[i] = per-block sum of g^2 over n floats;
+ *   needs mtam_sqnorm_blocks(n) floats.
+ * mtam_clip_scale: scale[0] = clip * min(1/norm, 1/clip), scale[1] = norm, with
+ *   norm = sqrt(sum of all partials).
+ * mtam_adam: p, m, v updated from g * scale[0]; hyper [4] (device) =
+ *   lr_t, beta1, beta2, eps with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) formed by the caller.
+ *   sparse_form != 0: m = m*b1 + g*(1-b1) (IndexedSlices path, tables);
+ *   else m += (g-m)*(1-b1) (dense ApplyAdam kernel).
+ */
+int mtam_sqnorm_blocks(size_t n);
+int mtam_sqnorm_partial(const float *g, size_t n, float *partial, void *stream);
+int mtam_clip_scale(const float *partials, int n_partials, float clip_norm, float *scale,
+                    void *stream);
+int mtam_adam(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
+              const float *hyper, int sparse_form, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTAM_HIP_H */

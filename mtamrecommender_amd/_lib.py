@@ -1,0 +1,77 @@
+"""ctypes binding of ``csrc/libmtam_hip.so`` (the C ABI in include/mtam_hip.h).
+
+There is no CPU fallback: if the shared library is missing or an entry point
+fails, the caller gets an exception.  The product path never imports
+``oracle``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmtam_hip.so")
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+P = c_void_p       # device pointer
+
+# name -> (restype, argtypes); every symbol include/mtam_hip.h declares
+SIGNATURES = {
+    "mtam_last_error": (ctypes.c_char_p, []),
+    "mtam_version": (c_int, []),
+    "mtam_arch": (ctypes.c_char_p, []),
+    "mtam_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int,
+                              P, P, P, c_int, c_int, P]),
+    "mtam_colsum_atomic": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "mtam_emb_gather_partials": (c_int, [c_int, c_int]),
+    "mtam_emb_gather_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
+                                    P, P, P, P, P]),
+    "mtam_emb_scatter_partials": (c_int, [c_int, c_int]),
+    "mtam_emb_scatter_add_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
+                                         P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
+    "mtam_tagru_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
+    "mtam_tagru_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
+    "mtam_ta_attn_decode_save_floats": (c_int, [c_int, c_int]),
+    "mtam_ta_attn_decode_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
+                                        c_int, c_int, c_int, P, P, P]),
+    "mtam_ta_attn_decode_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P,
+                                        c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
+    "mtam_layer_norm_fwd": (c_int, [P, P, P, c_float, c_int, P, P, P]),
+    "mtam_layer_norm_bwd": (c_int, [P, P, P, c_int, P, P, P]),
+    "mtam_softmax_ce_partials": (c_int, [c_int, c_int]),
+    "mtam_softmax_ce": (c_int, [P, c_int, P, c_int, c_int, c_float, P, P, P, P, P]),
+    "mtam_loss_reduce": (c_int, [P, c_int, P, c_int, c_float, c_float, P, P]),
+    "mtam_topk": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
+    "mtam_sqnorm_blocks": (c_int, [c_size_t]),
+    "mtam_sqnorm_partial": (c_int, [P, c_size_t, P, P]),
+    "mtam_clip_scale": (c_int, [P, c_int, c_float, P, P]),
+    "mtam_adam": (c_int, [P, P, P, P, c_size_t, P, P, c_int, P]),
+}
+
+_lib = None
+
+
+class MtamHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise if it was not built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MtamHipError(
+            "libmtam_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C mtamrecommender_amd/csrc`" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mtam_last_error()
+        raise MtamHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))

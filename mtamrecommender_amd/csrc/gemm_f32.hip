@@ -1,0 +1,282 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32) with fused
+// epilogues.  Replaces tf.layers.dense / tf.matmul and their gradients on the
+// time-aware path (see include/mtam_hip.h for the reference lines).
+//
+// Tiling: one 256-thread workgroup (4 waves, one per SIMD) owns a 64x64 tile of
+// C; each wave owns a 32x32 quadrant and accumulates it in 16 registers with
+// one MFMA per two k.  The fp32 MFMA is an exact k-ordered fmaf chain, so the
+// result of one output element does not depend on the tile it falls in.
+// Operands are staged global -> registers -> LDS in k-major order
+// (As[k][m], Bs[k][n]) so that the MFMA fragment reads (lane = m or n) are
+// bank-conflict free; the next k-tile's global loads are in flight while the
+// current one is multiplied.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDK = 65;  // LDS row stride when the source is k-contiguous (transposing write)
+constexpr int LDM = 68;  // LDS row stride when the source is m/n-contiguous (row write, 16-B aligned)
+
+struct GemmArgs {
+  const float *A, *B;
+  float *C;
+  const float *bias, *aux_in;
+  float *aux_out;
+  int M, N, K, lda, ldb, ldc, ld_aux;
+  int k_chunk;
+  int vecA, vecB;
+  int tiles_n;
+};
+
+// Source laid out src[r][k] (k contiguous): tile of 64 rows x 32 k.
+__device__ __forceinline__ void load_kcontig(const float *__restrict__ src, int ld, int rows, int r0,
+                                             int k0, int kend, bool vec, float4 (&reg)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = t + 256 * i;
+    const int r = r0 + (idx >> 3);
+    const int k = k0 + 4 * (idx & 7);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+      const float *p = src + (size_t)r * ld + k;
+      if (vec && k + 3 < kend) {
+        v = *reinterpret_cast<const float4 *>(p);
+      } else {
+        if (k + 0 < kend) v.x = p[0];
+        if (k + 1 < kend) v.y = p[1];
+        if (k + 2 < kend) v.z = p[2];
+        if (k + 3 < kend) v.w = p[3];
+      }
+    }
+    reg[i] = v;
+  }
+}
+__device__ __forceinline__ void store_kcontig(float *__restrict__ S, const float4 (&reg)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = t + 256 * i;
+    const int r = idx >> 3;
+    const int k = 4 * (idx & 7);
+    S[(k + 0) * LDK + r] = reg[i].x;
+    S[(k + 1) * LDK + r] = reg[i].y;
+    S[(k + 2) * LDK + r] = reg[i].z;
+    S[(k + 3) * LDK + r] = reg[i].w;
+  }
+}
+
+// Source laid out src[k][c] (c contiguous): tile of 32 k x 64 columns.
+__device__ __forceinline__ void load_ccontig(const float *__restrict__ src, int ld, int cols, int c0,
+                                             int k0, int kend, bool vec, float4 (&reg)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = t + 256 * i;
+    const int k = k0 + (idx >> 4);
+    const int c = c0 + 4 * (idx & 15);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < kend) {
+      const float *p = src + (size_t)k * ld + c;
+      if (vec && c + 3 < cols) {
+        v = *reinterpret_cast<const float4 *>(p);
+      } else {
+        if (c + 0 < cols) v.x = p[0];
+        if (c + 1 < cols) v.y = p[1];
+        if (c + 2 < cols) v.z = p[2];
+        if (c + 3 < cols) v.w = p[3];
+      }
+    }
+    reg[i] = v;
+  }
+}
+__device__ __forceinline__ void store_ccontig(float *__restrict__ S, const float4 (&reg)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = t + 256 * i;
+    const int k = idx >> 4;
+    const int c = 4 * (idx & 15);
+    *reinterpret_cast<float4 *>(&S[k * LDM + c]) = reg[i];
+  }
+}
+
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float As[BK * LDM];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDM];
+  constexpr int LDA_S = TA ? LDM : LDK;
+  constexpr int LDB_S = TB ? LDK : LDM;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // 1-D tile index (grid.y is capped at 65535; V/64 is not), split-K slice on grid.y
+  const int m0 = (blockIdx.x / p.tiles_n) * BM, n0 = (blockIdx.x % p.tiles_n) * BN;
+  const int kbeg = blockIdx.y * p.k_chunk;
+  const int kend = min(p.K, kbeg + p.k_chunk);
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  float4 ra[2], rb[2];
+  auto load_tiles = [&](int k0) {
+    if (TA) load_ccontig(p.A, p.lda, p.M, m0, k0, kend, p.vecA, ra);
+    else    load_kcontig(p.A, p.lda, p.M, m0, k0, kend, p.vecA, ra);
+    if (TB) load_kcontig(p.B, p.ldb, p.N, n0, k0, kend, p.vecB, rb);
+    else    load_ccontig(p.B, p.ldb, p.N, n0, k0, kend, p.vecB, rb);
+  };
+  auto store_tiles = [&]() {
+    if (TA) store_ccontig(As, ra); else store_kcontig(As, ra);
+    if (TB) store_kcontig(Bs, rb); else store_ccontig(Bs, rb);
+  };
+
+  if (kbeg < kend) {
+    load_tiles(kbeg);
+    store_tiles();
+    __syncthreads();
+    const int a_off = (lane >> 5) * LDA_S + wm * 32 + (lane & 31);
+    const int b_off = (lane >> 5) * LDB_S + wn * 32 + (lane & 31);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      const bool more = (k0 + BK) < kend;
+      if (more) load_tiles(k0 + BK);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        const float a = As[kk * LDA_S + a_off];
+        const float b = Bs[kk * LDB_S + b_off];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        store_tiles();
+        __syncthreads();
+      }
+    }
+  }
+
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int gn = n0 + wn * 32 + (lane & 31);
+  if (gn >= p.N) return;
+  float bias = 0.f;
+  if (EPI == MTAM_EPI_BIAS || EPI == MTAM_EPI_BIAS_RELU) bias = p.bias[gn];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (gm >= p.M) continue;
+    float v = acc[r];
+    float *c = p.C + (size_t)gm * p.ldc + gn;
+    if (EPI == MTAM_EPI_STORE) {
+      *c = v;
+    } else if (EPI == MTAM_EPI_BIAS) {
+      *c = v + bias;
+    } else if (EPI == MTAM_EPI_BIAS_RELU) {
+      *c = fmaxf(v + bias, 0.f);
+    } else if (EPI == MTAM_EPI_RELU_ADD) {
+      const size_t o = (size_t)gm * p.ld_aux + gn;
+      v = fmaxf(v, 0.f);
+      p.aux_out[o] = v;
+      *c = v + p.aux_in[o];
+    } else if (EPI == MTAM_EPI_ACCUM) {
+      *c += v;
+    } else if (EPI == MTAM_EPI_ACCUM_MASK) {
+      const size_t o = (size_t)gm * p.ld_aux + gn;
+      v += *c;
+      *c = v;
+      p.aux_out[o] = (p.aux_in[o] > 0.f) ? v : 0.f;
+    } else {  // MTAM_EPI_ATOMIC
+      atomicAdd(c, v);
+    }
+  }
+}
+
+template <bool TA, bool TB>
+void launch_epi(int epi, dim3 grid, hipStream_t s, const GemmArgs &a) {
+  switch (epi) {
+    case MTAM_EPI_STORE: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_STORE>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_BIAS: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_BIAS>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_BIAS_RELU>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_RELU_ADD: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_RELU_ADD>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ACCUM>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_ACCUM_MASK: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ACCUM_MASK>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ATOMIC>), grid, dim3(256), 0, s, a); break;
+  }
+}
+
+}  // namespace
+
+extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                             const float *B, int ldb, float *C, int ldc, int epilogue,
+                             const float *bias, const float *aux_in, float *aux_out, int ld_aux,
+                             int split_k, void *stream) {
+  MTAM_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive (got %d %d %d)", M, N, K);
+  MTAM_CHECK_ARG(A && B && C, "gemm: null operand");
+  MTAM_CHECK_ARG(epilogue >= MTAM_EPI_STORE && epilogue <= MTAM_EPI_ATOMIC, "gemm: bad epilogue %d", epilogue);
+  MTAM_CHECK_ARG(lda >= (trans_a ? M : K), "gemm: lda %d too small", lda);
+  MTAM_CHECK_ARG(ldb >= (trans_b ? K : N), "gemm: ldb %d too small", ldb);
+  MTAM_CHECK_ARG(ldc >= N, "gemm: ldc %d too small", ldc);
+  if (epilogue == MTAM_EPI_BIAS || epilogue == MTAM_EPI_BIAS_RELU)
+    MTAM_CHECK_ARG(bias != nullptr, "gemm: bias epilogue without bias");
+  if (epilogue == MTAM_EPI_RELU_ADD || epilogue == MTAM_EPI_ACCUM_MASK)
+    MTAM_CHECK_ARG(aux_in && aux_out && ld_aux >= N, "gemm: aux epilogue needs aux_in/aux_out/ld_aux");
+  if (split_k < 1) split_k = 1;
+  MTAM_CHECK_ARG(split_k == 1 || epilogue == MTAM_EPI_ATOMIC, "gemm: split_k > 1 needs the atomic epilogue");
+  int k_chunk = (K + split_k - 1) / split_k;
+  k_chunk = ((k_chunk + BK - 1) / BK) * BK;
+  split_k = (K + k_chunk - 1) / k_chunk;
+  const long gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+  MTAM_CHECK_ARG(gx * gy <= 0x7fffffffL && split_k <= 65535, "gemm: grid too large");
+
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux_in = aux_in; a.aux_out = aux_out;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux = ld_aux;
+  a.k_chunk = k_chunk;
+  a.vecA = (lda % 4 == 0) && mtam_aligned16(A);
+  a.vecB = (ldb % 4 == 0) && mtam_aligned16(B);
+  a.tiles_n = (int)gx;
+  dim3 grid((unsigned)(gx * gy), (unsigned)split_k, 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (trans_a) {
+    if (trans_b) launch_epi<true, true>(epilogue, grid, s, a);
+    else         launch_epi<true, false>(epilogue, grid, s, a);
+  } else {
+    if (trans_b) launch_epi<false, true>(epilogue, grid, s, a);
+    else         launch_epi<false, false>(epilogue, grid, s, a);
+  }
+  MTAM_CHECK_LAUNCH("gemm");
+  return MTAM_OK;
+}
+
+// ---------------------------------------------------------------- column sums
+namespace {
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ in, int rows, int cols,
+                                                     int ld, int rows_per_block, float *__restrict__ out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rr = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < cols)
+    for (int r = r0 + rr; r < r1; r += 4) s += in[(size_t)r * ld + c];
+  part[rr][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rr == 0 && c < cols) {
+    s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    atomicAdd(out + c, s);
+  }
+}
+}  // namespace
+
+extern "C" int mtam_colsum_atomic(const float *in, int rows, int cols, int ld, float *out, void *stream) {
+  MTAM_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld >= cols, "colsum: bad arguments");
+  const int rows_per_block = 64;
+  dim3 grid((cols + 63) / 64, (rows + rows_per_block - 1) / rows_per_block);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, rows, cols,
+                     ld, rows_per_block, out);
+  MTAM_CHECK_LAUNCH("colsum");
+  return MTAM_OK;
+}

@@ -1,0 +1,345 @@
+// Head of the model: contrib layer_norm, full-catalog softmax cross entropy and
+// top-K over the catalog.
+//   layer_norm : Model/Modules/net_utils.py:229-232 (tf.contrib.layers.layer_norm)
+//   softmax CE : Model/base_model.py:316-322 (log_softmax + one_hot + reduce_mean)
+//   top-K      : Model/base_model.py:194-200 (tf.nn.top_k x5 over pred @ table^T)
+// The logits themselves come from mtam_gemm_f32 (pred @ table^T).
+#include "common.h"
+
+namespace {
+
+constexpr int D = MTAM_D;
+constexpr int CE_CHUNK = 4096;   // logits per workgroup in the softmax passes
+
+// ------------------------------------------------------------- layer norm
+__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float *__restrict__ x, const float *beta,
+                                                             const float *gamma, float eps, int rows,
+                                                             float *__restrict__ y, float *__restrict__ save) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float x0 = x[(size_t)row * D + lane], x1 = x[(size_t)row * D + 64 + lane];
+  const float mean = wave_sum(x0 + x1) / (float)D;
+  const float d0 = x0 - mean, d1 = x1 - mean;
+  const float var = wave_sum(d0 * d0 + d1 * d1) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  // nn.batch_normalization form: x * inv + (beta - mean * inv)
+  const float i0 = rstd * gamma[lane], i1 = rstd * gamma[64 + lane];
+  y[(size_t)row * D + lane] = x0 * i0 + (beta[lane] - mean * i0);
+  y[(size_t)row * D + 64 + lane] = x1 * i1 + (beta[64 + lane] - mean * i1);
+  if (save) {
+    save[(size_t)row * (D + 1) + lane] = d0 * rstd;
+    save[(size_t)row * (D + 1) + 64 + lane] = d1 * rstd;
+    if (lane == 0) save[(size_t)row * (D + 1) + D] = rstd;
+  }
+}
+
+__global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float *__restrict__ dy, const float *gamma,
+                                                             const float *__restrict__ save, int rows,
+                                                             float *__restrict__ dx, float *d_bg) {
+  __shared__ float sb[4][D], sg[4][D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = blockIdx.x * 4 + wv;
+  float b0 = 0.f, b1 = 0.f, g0 = 0.f, g1 = 0.f;
+  if (row < rows) {
+    const float y0 = dy[(size_t)row * D + lane], y1 = dy[(size_t)row * D + 64 + lane];
+    const float h0 = save[(size_t)row * (D + 1) + lane], h1 = save[(size_t)row * (D + 1) + 64 + lane];
+    const float rstd = save[(size_t)row * (D + 1) + D];
+    const float a0 = y0 * gamma[lane], a1 = y1 * gamma[64 + lane];
+    const float m1 = wave_sum(a0 + a1) / (float)D;
+    const float m2 = wave_sum(a0 * h0 + a1 * h1) / (float)D;
+    dx[(size_t)row * D + lane] = rstd * (a0 - m1 - h0 * m2);
+    dx[(size_t)row * D + 64 + lane] = rstd * (a1 - m1 - h1 * m2);
+    b0 = y0; b1 = y1; g0 = y0 * h0; g1 = y1 * h1;
+  }
+  sb[wv][lane] = b0; sb[wv][64 + lane] = b1; sg[wv][lane] = g0; sg[wv][64 + lane] = g1;
+  __syncthreads();
+  if (threadIdx.x < D) {
+    const int c = threadIdx.x;
+    atomicAdd(d_bg + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+    atomicAdd(d_bg + D + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+  }
+}
+
+// ------------------------------------------------------------- softmax CE
+__device__ __forceinline__ float block_reduce_max(float v, float *red) {
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return v;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float *red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ce_partial_kernel(const float *__restrict__ logits, int ld, int V,
+                                                         int chunks, float *__restrict__ partial) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, c = blockIdx.x;
+  const float *row = logits + (size_t)b * ld;
+  const int v0 = c * CE_CHUNK, v1 = min(V, v0 + CE_CHUNK);
+  float vals[CE_CHUNK / 256];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < CE_CHUNK / 256; ++i) {
+    const int v = v0 + threadIdx.x + 256 * i;
+    vals[i] = (v < v1) ? row[v] : -INFINITY;
+    m = fmaxf(m, vals[i]);
+  }
+  m = block_reduce_max(m, red);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CE_CHUNK / 256; ++i) s += expf(vals[i] - m);   // exp(-inf) = 0 for the tail
+  s = block_reduce_sum(s, red);
+  if (threadIdx.x == 0) {
+    partial[((size_t)b * chunks + c) * 2 + 0] = m;
+    partial[((size_t)b * chunks + c) * 2 + 1] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float *__restrict__ logits, int ld,
+                                                        const int32_t *__restrict__ target, int V, int chunks,
+                                                        const float *__restrict__ partial,
+                                                        float *__restrict__ lse, float *__restrict__ ce) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float *pp = partial + (size_t)b * chunks * 2;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < chunks; c += 256) m = fmaxf(m, pp[2 * c]);
+  m = block_reduce_max(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < chunks; c += 256) s += pp[2 * c + 1] * expf(pp[2 * c] - m);
+  s = block_reduce_sum(s, red);
+  if (threadIdx.x == 0) {
+    const float l = m + logf(s);
+    const int t = min(max(target[b], 0), V - 1);
+    lse[b] = l;
+    ce[b] = l - logits[(size_t)b * ld + t];
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_grad_kernel(const float *__restrict__ logits, int ld,
+                                                      const int32_t *__restrict__ target, int V,
+                                                      const float *__restrict__ lse, float scale,
+                                                      float *__restrict__ d_logits) {
+  const int b = blockIdx.y;
+  const float l = lse[b];
+  const int t = target[b];
+  const int v0 = blockIdx.x * CE_CHUNK;
+#pragma unroll
+  for (int i = 0; i < CE_CHUNK / 256; ++i) {
+    const int v = v0 + threadIdx.x + 256 * i;
+    if (v < V) {
+      const float pr = expf(logits[(size_t)b * ld + v] - l);
+      d_logits[(size_t)b * ld + v] = (pr - (v == t ? 1.0f : 0.0f)) * scale;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float *__restrict__ l2_partial, int n_l2,
+                                                          const float *__restrict__ ce, int B, float reg,
+                                                          float ce_scale, float *__restrict__ loss) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_l2; i += 256) s += l2_partial[i];
+  const float l2 = 0.5f * block_reduce_sum(s, red);
+  s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s += ce[i];
+  const float ces = block_reduce_sum(s, red);
+  if (threadIdx.x == 0) {
+    loss[0] = reg * l2 + ce_scale * ces;
+    loss[1] = l2;
+    loss[2] = ces / (float)B;
+  }
+}
+
+// ------------------------------------------------------------------ top-K
+// Radix select on an order-preserving integer image of the float (3 digit
+// passes of 11/11/10 bits), then an index-ordered sweep that keeps everything
+// above the threshold and the lowest-index ties, then a 64-wide bitonic sort of
+// (value desc, index asc).  One workgroup per row.
+__device__ __forceinline__ uint32_t order_key(float f) {
+  uint32_t u = __float_as_uint(f);
+  if (u == 0x80000000u) u = 0u;                       // -0.0 == +0.0
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ scores, int ld, int V, int k,
+                                                   int32_t *__restrict__ idx_out, float *__restrict__ val_out) {
+  __shared__ uint32_t hist[2048];
+  __shared__ uint32_t scan[256];
+  __shared__ uint32_t sel_bin, sel_above;
+  __shared__ uint32_t cand_key[64], cand_idx[64];
+  __shared__ uint32_t n_gt, eq_base;
+  __shared__ uint32_t wave_cnt[4];
+
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float *s = scores + (size_t)row * ld;
+  const int kk = min(k, V);
+
+  uint32_t prefix = 0;        // selected high bits so far
+  uint32_t need = kk;         // how many still to take from the current digit range
+  const int shifts[3] = {21, 10, 0};
+  const int bits[3] = {11, 11, 10};
+  for (int pass = 0; pass < 3; ++pass) {
+    const int sh = shifts[pass], nb = 1 << bits[pass];
+    for (int i = tid; i < 2048; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int v = tid; v < V; v += 256) {
+      const uint32_t key = order_key(s[v]);
+      const bool match = (pass == 0) || ((key >> (sh + bits[pass])) == prefix);
+      if (match) atomicAdd(&hist[(key >> sh) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    // suffix sums over groups of 8 bins
+    uint32_t c = 0;
+    for (int i = 0; i < 8; ++i) c += hist[tid * 8 + i];
+    scan[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const uint32_t add = (tid + off < 256) ? scan[tid + off] : 0u;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    const uint32_t above = (tid + 1 < 256) ? scan[tid + 1] : 0u;   // elements in bins above my group
+    if (above < need && scan[tid] >= need) {
+      uint32_t acc = above;
+      for (int i = 7; i >= 0; --i) {
+        const uint32_t h = hist[tid * 8 + i];
+        if (acc + h >= need) { sel_bin = tid * 8 + i; sel_above = acc; break; }
+        acc += h;
+      }
+    }
+    __syncthreads();
+    prefix = (prefix << bits[pass]) | sel_bin;
+    need -= sel_above;
+    __syncthreads();
+  }
+  const uint32_t thr = prefix;          // key of the kk-th largest element; `need` ties to take (>= 1)
+
+  if (tid == 0) { n_gt = 0; eq_base = 0; }
+  if (tid < 64) { cand_key[tid] = 0; cand_idx[tid] = 0xffffffffu; }
+  __syncthreads();
+  const uint32_t gt_total = kk - need;  // number of elements strictly above the threshold
+  for (int v0 = 0; v0 < V; v0 += 256) {
+    const int v = v0 + tid;
+    const uint32_t key = (v < V) ? order_key(s[v]) : 0u;
+    const bool gt = (v < V) && key > thr;
+    const bool eq = (v < V) && key == thr;
+    if (gt) {
+      const uint32_t slot = atomicAdd(&n_gt, 1u);
+      cand_key[slot] = key;
+      cand_idx[slot] = v;
+    }
+    // index-ordered rank of the ties inside this 256-chunk
+    const unsigned long long bal = __ballot(eq);
+    const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    uint32_t base = eq_base;
+    for (int q = 0; q < wv; ++q) base += wave_cnt[q];
+    if (eq) {
+      const uint32_t rank = base + before;
+      if (rank < need) {
+        cand_key[gt_total + rank] = key;
+        cand_idx[gt_total + rank] = v;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) eq_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  __syncthreads();
+
+  // bitonic sort of 64 (key, index) pairs, descending by key then ascending by index
+  if (wv == 0) {
+    unsigned long long item = ((unsigned long long)cand_key[lane] << 32) |
+                              (unsigned long long)(0xffffffffu - cand_idx[lane]);
+    for (int size = 2; size <= 64; size <<= 1) {
+      for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+        const unsigned long long other = __shfl_xor(item, stride, 64);
+        const bool up = ((lane & size) == 0);           // descending overall
+        const bool lower = ((lane & stride) == 0);
+        const bool keep_max = (up == lower);
+        const unsigned long long mx = item > other ? item : other;
+        const unsigned long long mn = item > other ? other : item;
+        item = keep_max ? mx : mn;
+      }
+    }
+    if (lane < k) {
+      const uint32_t key = (uint32_t)(item >> 32);
+      const uint32_t idx = 0xffffffffu - (uint32_t)(item & 0xffffffffu);
+      idx_out[(size_t)row * k + lane] = (lane < kk) ? (int32_t)idx : -1;
+      if (val_out) val_out[(size_t)row * k + lane] = (lane < kk) ? key_to_float(key) : 0.f;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mtam_layer_norm_fwd(const float *x, const float *beta, const float *gamma, float eps,
+                                   int rows, float *y, float *save, void *stream) {
+  MTAM_CHECK_ARG(x && beta && gamma && y && rows > 0, "layer_norm_fwd: bad arguments");
+  hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, beta, gamma, eps, rows, y, save);
+  MTAM_CHECK_LAUNCH("layer_norm_fwd");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_layer_norm_bwd(const float *d_y, const float *gamma, const float *save, int rows,
+                                   float *d_x, float *d_bg, void *stream) {
+  MTAM_CHECK_ARG(d_y && gamma && save && d_x && d_bg && rows > 0, "layer_norm_bwd: bad arguments");
+  hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d_y, gamma, save, rows, d_x, d_bg);
+  MTAM_CHECK_LAUNCH("layer_norm_bwd");
+  return MTAM_OK;
+}
+
+static int ce_chunks(int V) { return (V + CE_CHUNK - 1) / CE_CHUNK; }
+
+extern "C" int mtam_softmax_ce_partials(int B, int V) { return B * ce_chunks(V) * 2; }
+
+extern "C" int mtam_softmax_ce(const float *logits, int ld, const int32_t *target, int B, int V,
+                               float grad_scale, float *lse, float *ce, float *d_logits, float *partial,
+                               void *stream) {
+  MTAM_CHECK_ARG(logits && target && lse && ce && partial, "softmax_ce: null argument");
+  MTAM_CHECK_ARG(B > 0 && B <= 65535 && V > 0 && ld >= V, "softmax_ce: bad shape B=%d V=%d ld=%d", B, V, ld);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int chunks = ce_chunks(V);
+  hipLaunchKernelGGL(ce_partial_kernel, dim3(chunks, B), dim3(256), 0, s, logits, ld, V, chunks, partial);
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(B), dim3(256), 0, s, logits, ld, target, V, chunks, partial, lse, ce);
+  if (d_logits)
+    hipLaunchKernelGGL(ce_grad_kernel, dim3(chunks, B), dim3(256), 0, s, logits, ld, target, V, lse,
+                       grad_scale, d_logits);
+  MTAM_CHECK_LAUNCH("softmax_ce");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_loss_reduce(const float *l2_partial, int n_l2, const float *ce, int B, float reg,
+                                float ce_scale, float *loss, void *stream) {
+  MTAM_CHECK_ARG(l2_partial && ce && loss && n_l2 >= 0 && B > 0, "loss_reduce: bad arguments");
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), l2_partial,
+                     n_l2, ce, B, reg, ce_scale, loss);
+  MTAM_CHECK_LAUNCH("loss_reduce");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_topk(const float *scores, int ld, int rows, int V, int k, int32_t *idx_out,
+                         float *val_out, void *stream) {
+  MTAM_CHECK_ARG(scores && idx_out && rows > 0 && V > 0 && ld >= V, "topk: bad arguments");
+  MTAM_CHECK_ARG(k >= 1 && k <= 64, "topk: k must be in [1, 64] (got %d)", k);
+  hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), scores, ld, V, k,
+                     idx_out, val_out);
+  MTAM_CHECK_LAUNCH("topk");
+  return MTAM_OK;
+}

@@ -1,0 +1,405 @@
+// Time-aware multi-head attention, decoder form (T_q = 1), one block of
+// vanilla_attention: Model/Modules/time_aware_attention.py:215-456 as wired by
+// Model/MTAMRec_model.py:83-90, including residual and normalize() (:7-34).
+//
+// With one query per sample, Q.K^T is a 1xL row per head: there
+// is no dense contraction to put on MFMA, the work is streaming the sample's
+// L key / value / raw-key rows once (3 x L x 512 B) and a few wave reductions.
+// One 256-thread workgroup per sample:
+//   q -> [Q | q.Wt] by an in-kernel mat-vec over the L2-resident [D,2D] weight,
+//   half a wave per key row (32 lanes x 16 B) for the two dot products,
+//   wavefront-reduced masked softmax per head, weighted V sum, residual, LN.
+#include "common.h"
+
+namespace {
+
+constexpr int D = MTAM_D;
+constexpr int MAXL = 256;
+constexpr int MAXH = 8;
+// -2**32 + 1 (time_aware_attention.py:392); rounds to -2^32 in float32 exactly as in TF
+constexpr float MASK_VALUE = -4294967295.0f;
+
+__device__ __forceinline__ int save_floats(int L, int H) { return 3 * D + 3 * L + 2 * H * L + 1; }
+
+struct FwdArgs {
+  const float *dec_in, *x, *kv;
+  int ld_kv, k_off, v_off;
+  const float *t_query, *t_keys;
+  const int32_t *seq_len;
+  const float *wqt, *bq, *tparams, *ln_beta, *ln_gamma;
+  int B, L, H;
+  float *dec_out, *save;
+};
+
+__device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+__global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float q_s[D];
+  __shared__ __attribute__((aligned(16))) float Q_s[D];
+  __shared__ __attribute__((aligned(16))) float qt_s[D];
+  __shared__ float sc_s[MAXH][MAXL];
+  __shared__ float qk_s[MAXH][MAXL];
+  __shared__ float a_s[MAXL], dk_s[MAXL], sg_s[MAXL];
+  __shared__ float o_part[2][D];
+  __shared__ float red[4];
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int L = p.L, H = p.H;
+  const int sl = min(max(p.seq_len[b], 0), L);
+  const size_t row0 = (size_t)b * L;
+  const int lanes_per_head = 32 / H;
+  const float inv_div = sqrtf((float)(D / H));
+
+  if (tid < D) q_s[tid] = p.dec_in[(size_t)b * D + tid];
+  __syncthreads();
+
+  // [Q | qt] = q . [Wq | Wt]; thread = output column, coalesced weight reads
+  {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < D; k += 4) {
+      const float4 qv = *reinterpret_cast<const float4 *>(&q_s[k]);
+      acc = fmaf(qv.x, p.wqt[(size_t)(k + 0) * (2 * D) + tid], acc);
+      acc = fmaf(qv.y, p.wqt[(size_t)(k + 1) * (2 * D) + tid], acc);
+      acc = fmaf(qv.z, p.wqt[(size_t)(k + 2) * (2 * D) + tid], acc);
+      acc = fmaf(qv.w, p.wqt[(size_t)(k + 3) * (2 * D) + tid], acc);
+    }
+    if (tid < D) Q_s[tid] = fmaxf(acc + p.bq[tid], 0.f);
+    else qt_s[tid - D] = acc;
+  }
+  __syncthreads();
+
+  // scores: half a wave per key row
+  {
+    const int hw = tid >> 5, li = tid & 31;
+    const float4 Q4 = *reinterpret_cast<const float4 *>(&Q_s[4 * li]);
+    const float4 T4 = *reinterpret_cast<const float4 *>(&qt_s[4 * li]);
+    const float tq = p.t_query[b];
+    for (int j = hw; j < L; j += 8) {
+      if (j < sl) {
+        const float4 kq = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.k_off + 4 * li]);
+        const float4 xq = *reinterpret_cast<const float4 *>(&p.x[(row0 + j) * D + 4 * li]);
+        const float dK = group_sum(dot4(kq, Q4), lanes_per_head);
+        const float dA = group_sum(dot4(xq, T4), 32);
+        const float a = tanhf(dA);
+        const float delta = logf(fabsf(tq - p.t_keys[row0 + j]) + 1.0f);
+        const float dk = tanhf(delta * p.tparams[j] + p.tparams[L + j]);
+        const float g = p.tparams[2 * L + j] * dk + p.tparams[3 * L + j] * a + p.tparams[4 * L + j];
+        const float sg = sigmoidf_(g);
+        if ((li % lanes_per_head) == 0) {
+          const int h = li / lanes_per_head;
+          qk_s[h][j] = dK;
+          sc_s[h][j] = (dK * sg) / inv_div;
+        }
+        if (li == 0) { a_s[j] = a; dk_s[j] = dk; sg_s[j] = sg; }
+      } else {
+        if (li < H) { qk_s[li][j] = 0.f; sc_s[li][j] = MASK_VALUE; }
+        if (li == 0) { a_s[j] = 0.f; dk_s[j] = 0.f; sg_s[j] = 0.f; }
+      }
+    }
+  }
+  __syncthreads();
+
+  // masked softmax over keys, one wave per head
+  for (int h = w; h < H; h += 4) {
+    float m = -INFINITY;
+    for (int j = lane; j < L; j += 64) m = fmaxf(m, sc_s[h][j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < L; j += 64) {
+      const float e = expf(sc_s[h][j] - m);
+      sc_s[h][j] = e;
+      s += e;
+    }
+    s = wave_sum(s);
+    for (int j = lane; j < L; j += 64) sc_s[h][j] = sc_s[h][j] / s;
+  }
+  __syncthreads();
+
+  // O = W . V  (thread = channel, keys split in two halves)
+  {
+    const int c = tid & (D - 1), part = tid >> 7;
+    const int h = c / (D / H);
+    const int jmid = (sl + 1) / 2;
+    const int j0 = part ? jmid : 0, j1 = part ? sl : jmid;
+    float o = 0.f;
+    for (int j = j0; j < j1; ++j) o = fmaf(sc_s[h][j], p.kv[(row0 + j) * p.ld_kv + p.v_off + c], o);
+    o_part[part][c] = o;
+  }
+  __syncthreads();
+
+  // residual + normalize(eps = 1e-8): (y - mean) / sqrt(var + eps) * gamma + beta
+  float y = 0.f;
+  if (tid < D) {
+    y = o_part[0][tid] + o_part[1][tid] + q_s[tid];
+    const float s = wave_sum(y);
+    if (lane == 0) red[w] = s;
+  }
+  __syncthreads();
+  float diff = 0.f;
+  if (tid < D) {
+    const float mean = (red[0] + red[1]) / (float)D;
+    diff = y - mean;
+    const float s = wave_sum(diff * diff);
+    if (lane == 0) red[2 + w] = s;
+  }
+  __syncthreads();
+  if (tid < D) {
+    const float var = (red[2] + red[3]) / (float)D;
+    const float sd = sqrtf(var + 1e-8f);
+    const float xhat = diff / sd;
+    p.dec_out[(size_t)b * D + tid] = p.ln_gamma[tid] * xhat + p.ln_beta[tid];
+    if (p.save) {
+      float *sv = p.save + (size_t)b * save_floats(L, H);
+      sv[tid] = Q_s[tid];
+      sv[D + tid] = qt_s[tid];
+      sv[2 * D + tid] = xhat;
+      if (tid == 0) sv[3 * D + 3 * L + 2 * H * L] = 1.0f / sd;
+    }
+  }
+  if (p.save) {
+    float *sv = p.save + (size_t)b * save_floats(L, H) + 3 * D;
+    for (int j = tid; j < L; j += 256) {
+      sv[j] = a_s[j];
+      sv[L + j] = dk_s[j];
+      sv[2 * L + j] = sg_s[j];
+    }
+    for (int i = tid; i < H * L; i += 256) {
+      const int h = i / L, j = i - h * L;
+      sv[3 * L + i] = qk_s[h][j];
+      sv[3 * L + H * L + i] = sc_s[h][j];
+    }
+  }
+}
+
+struct BwdArgs {
+  const float *d_out, *dec_in, *x, *kv;
+  int ld_kv, k_off, v_off;
+  const float *t_query, *t_keys;
+  const int32_t *seq_len;
+  const float *wqt, *tparams, *ln_gamma, *save;
+  int B, L, H, accumulate_dx;
+  float *d_dec_in, *d_kv, *d_x, *d_qt_pre, *d_tparams_partial, *d_ln_partial;
+};
+
+__global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float dO_s[D];
+  __shared__ __attribute__((aligned(16))) float Q_s[D];
+  __shared__ __attribute__((aligned(16))) float qt_s[D];
+  __shared__ __attribute__((aligned(16))) float dqp_s[2 * D];
+  __shared__ float w_s[MAXH][MAXL];    // softmax weights
+  __shared__ float ds_s[MAXH][MAXL];   // dW, then dS, then d(QK)
+  __shared__ float dap_s[MAXL];
+  __shared__ __attribute__((aligned(16))) float partQ[8][D];
+  __shared__ __attribute__((aligned(16))) float partT[8][D];
+  __shared__ float red[4];
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int L = p.L, H = p.H;
+  const int sl = min(max(p.seq_len[b], 0), L);
+  const size_t row0 = (size_t)b * L;
+  const int lanes_per_head = 32 / H;
+  const float inv_div = sqrtf((float)(D / H));
+  const float *sv = p.save + (size_t)b * save_floats(L, H);
+  const float *sv_a = sv + 3 * D, *sv_dk = sv_a + L, *sv_sg = sv_dk + L;
+  const float *sv_qk = sv_sg + L, *sv_w = sv_qk + H * L;
+  const float rstd = sv_w[H * L];
+
+  // ---- normalize() backward
+  float dxh = 0.f, xhat = 0.f;
+  if (tid < D) {
+    const float dy = p.d_out[(size_t)b * D + tid];
+    xhat = sv[2 * D + tid];
+    p.d_ln_partial[((size_t)b * 2 + 0) * D + tid] = dy;
+    p.d_ln_partial[((size_t)b * 2 + 1) * D + tid] = dy * xhat;
+    dxh = dy * p.ln_gamma[tid];
+    const float s1 = wave_sum(dxh), s2 = wave_sum(dxh * xhat);
+    if (lane == 0) { red[w] = s1; red[2 + w] = s2; }
+    Q_s[tid] = sv[tid];
+    qt_s[tid] = sv[D + tid];
+  }
+  for (int i = tid; i < H * L; i += 256) {
+    const int h = i / L, j = i - h * L;
+    w_s[h][j] = sv_w[i];
+  }
+  __syncthreads();
+  float dres = 0.f;
+  if (tid < D) {
+    const float m1 = (red[0] + red[1]) / (float)D, m2 = (red[2] + red[3]) / (float)D;
+    dres = rstd * (dxh - m1 - xhat * m2);   // gradient of y = O + q
+    dO_s[tid] = dres;
+  }
+  __syncthreads();
+
+  const int hw = tid >> 5, li = tid & 31;
+  const int head_of_lane = li / lanes_per_head;
+  // ---- dW[h][j] = dO_h . V_j
+  {
+    const float4 dO4 = *reinterpret_cast<const float4 *>(&dO_s[4 * li]);
+    for (int j = hw; j < L; j += 8) {
+      if (j < sl) {
+        const float4 vq = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.v_off + 4 * li]);
+        const float dW = group_sum(dot4(vq, dO4), lanes_per_head);
+        if ((li % lanes_per_head) == 0) ds_s[head_of_lane][j] = dW;
+      } else if (li < H) {
+        ds_s[li][j] = 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- softmax backward: dS = W * (dW - sum_j W dW)
+  for (int h = w; h < H; h += 4) {
+    float s = 0.f;
+    for (int j = lane; j < sl; j += 64) s += w_s[h][j] * ds_s[h][j];
+    s = wave_sum(s);
+    for (int j = lane; j < L; j += 64) ds_s[h][j] = (j < sl) ? w_s[h][j] * (ds_s[h][j] - s) : 0.f;
+  }
+  __syncthreads();
+  // ---- gate backward, thread per key
+  for (int j = tid; j < L; j += 256) {
+    float g_w1 = 0.f, g_b1 = 0.f, g_ow1 = 0.f, g_ow2 = 0.f, g_ob = 0.f, dap = 0.f;
+    if (j < sl) {
+      const float sg = sv_sg[j], a = sv_a[j], dk = sv_dk[j];
+      float dsg = 0.f;
+      for (int h = 0; h < H; ++h) {
+        const float dS = ds_s[h][j];
+        dsg += dS * sv_qk[h * L + j];
+        ds_s[h][j] = dS * sg / inv_div;            // d(Q_h . K_hj)
+      }
+      dsg = dsg / inv_div;
+      const float dG = dsg * sg * (1.f - sg);
+      const float delta = logf(fabsf(p.t_query[b] - p.t_keys[row0 + j]) + 1.0f);
+      g_ow1 = dG * dk;
+      g_ow2 = dG * a;
+      g_ob = dG;
+      const float ddk = dG * p.tparams[2 * L + j] * (1.f - dk * dk);
+      g_w1 = ddk * delta;
+      g_b1 = ddk;
+      dap = dG * p.tparams[3 * L + j] * (1.f - a * a);
+    }
+    dap_s[j] = dap;
+    float *gp = p.d_tparams_partial + (size_t)b * 5 * L + j;
+    gp[0] = g_w1; gp[L] = g_b1; gp[2 * L] = g_ow1; gp[3 * L] = g_ow2; gp[4 * L] = g_ob;
+  }
+  __syncthreads();
+  // ---- per key: dK, dV (relu-masked), raw-key gradient; accumulate dQ, d(qt)
+  {
+    const float4 dO4 = *reinterpret_cast<const float4 *>(&dO_s[4 * li]);
+    const float4 Q4 = *reinterpret_cast<const float4 *>(&Q_s[4 * li]);
+    const float4 T4 = *reinterpret_cast<const float4 *>(&qt_s[4 * li]);
+    float4 aQ = make_float4(0.f, 0.f, 0.f, 0.f), aT = aQ;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = hw; j < L; j += 8) {
+      float *dk_row = p.d_kv + (row0 + j) * p.ld_kv + p.k_off + 4 * li;
+      float *dv_row = p.d_kv + (row0 + j) * p.ld_kv + p.v_off + 4 * li;
+      float *dx_row = p.d_x + (row0 + j) * D + 4 * li;
+      if (j < sl) {
+        const float4 kq = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.k_off + 4 * li]);
+        const float4 vq = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.v_off + 4 * li]);
+        const float4 xq = *reinterpret_cast<const float4 *>(&p.x[(row0 + j) * D + 4 * li]);
+        const float wj = w_s[head_of_lane][j], dqk = ds_s[head_of_lane][j], dap = dap_s[j];
+        float4 dv, dk;
+        dv.x = vq.x > 0.f ? wj * dO4.x : 0.f; dv.y = vq.y > 0.f ? wj * dO4.y : 0.f;
+        dv.z = vq.z > 0.f ? wj * dO4.z : 0.f; dv.w = vq.w > 0.f ? wj * dO4.w : 0.f;
+        dk.x = kq.x > 0.f ? dqk * Q4.x : 0.f; dk.y = kq.y > 0.f ? dqk * Q4.y : 0.f;
+        dk.z = kq.z > 0.f ? dqk * Q4.z : 0.f; dk.w = kq.w > 0.f ? dqk * Q4.w : 0.f;
+        *reinterpret_cast<float4 *>(dv_row) = dv;
+        *reinterpret_cast<float4 *>(dk_row) = dk;
+        float4 dx = make_float4(dap * T4.x, dap * T4.y, dap * T4.z, dap * T4.w);
+        if (p.accumulate_dx) {
+          const float4 o = *reinterpret_cast<const float4 *>(dx_row);
+          dx.x += o.x; dx.y += o.y; dx.z += o.z; dx.w += o.w;
+        }
+        *reinterpret_cast<float4 *>(dx_row) = dx;
+        aQ.x = fmaf(dqk, kq.x, aQ.x); aQ.y = fmaf(dqk, kq.y, aQ.y);
+        aQ.z = fmaf(dqk, kq.z, aQ.z); aQ.w = fmaf(dqk, kq.w, aQ.w);
+        aT.x = fmaf(dap, xq.x, aT.x); aT.y = fmaf(dap, xq.y, aT.y);
+        aT.z = fmaf(dap, xq.z, aT.z); aT.w = fmaf(dap, xq.w, aT.w);
+      } else {
+        *reinterpret_cast<float4 *>(dv_row) = zero4;
+        *reinterpret_cast<float4 *>(dk_row) = zero4;
+        if (!p.accumulate_dx) *reinterpret_cast<float4 *>(dx_row) = zero4;
+      }
+    }
+    *reinterpret_cast<float4 *>(&partQ[hw][4 * li]) = aQ;
+    *reinterpret_cast<float4 *>(&partT[hw][4 * li]) = aT;
+  }
+  __syncthreads();
+  if (tid < D) {
+    float dQ = 0.f, dT = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { dQ += partQ[q][tid]; dT += partT[q][tid]; }
+    const float dQp = (Q_s[tid] > 0.f) ? dQ : 0.f;
+    dqp_s[tid] = dQp;
+    dqp_s[D + tid] = dT;
+    p.d_qt_pre[(size_t)b * 2 * D + tid] = dQp;
+    p.d_qt_pre[(size_t)b * 2 * D + D + tid] = dT;
+  }
+  __syncthreads();
+  // ---- d(dec_in)[c] = residual + [dQpre | dqt] . wqt[c, :]^T ; a wave per row, lanes along n
+  {
+    float dq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[i] = dqp_s[lane + 64 * i];
+    for (int c = w; c < D; c += 4) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s = fmaf(dq[i], p.wqt[(size_t)c * (2 * D) + lane + 64 * i], s);
+      s = wave_sum(s);
+      if (lane == 0) p.d_dec_in[(size_t)b * D + c] = s + dO_s[c];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mtam_ta_attn_decode_save_floats(int L, int H) { return 3 * D + 3 * L + 2 * H * L + 1; }
+
+static int check_attn_common(const char *name, int B, int L, int H, int ld_kv, int k_off, int v_off,
+                             const float *kv, const float *x) {
+  MTAM_CHECK_ARG(B > 0 && L > 0 && L <= MAXL, "%s: need 0 < L <= %d (got %d)", name, MAXL, L);
+  MTAM_CHECK_ARG(H == 1 || H == 2 || H == 4 || H == 8, "%s: num_heads must be 1, 2, 4 or 8 (got %d)", name, H);
+  MTAM_CHECK_ARG(ld_kv % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && k_off + D <= ld_kv && v_off + D <= ld_kv,
+                 "%s: bad kv layout", name);
+  MTAM_CHECK_ARG(mtam_aligned16(kv) && mtam_aligned16(x), "%s: kv and x must be 16-byte aligned", name);
+  return MTAM_OK;
+}
+
+extern "C" int mtam_ta_attn_decode_fwd(const float *dec_in, const float *x, const float *kv, int ld_kv,
+                                       int k_off, int v_off, const float *t_query, const float *t_keys,
+                                       const int32_t *seq_len, const float *wqt, const float *bq,
+                                       const float *tparams, const float *ln_beta, const float *ln_gamma,
+                                       int B, int L, int H, float *dec_out, float *save, void *stream) {
+  MTAM_CHECK_ARG(dec_in && x && kv && t_query && t_keys && seq_len && wqt && bq && tparams && ln_beta &&
+                     ln_gamma && dec_out,
+                 "ta_attn_decode_fwd: null argument");
+  int rc = check_attn_common("ta_attn_decode_fwd", B, L, H, ld_kv, k_off, v_off, kv, x);
+  if (rc) return rc;
+  FwdArgs a{dec_in, x, kv, ld_kv, k_off, v_off, t_query, t_keys, seq_len, wqt, bq, tparams,
+            ln_beta, ln_gamma, B, L, H, dec_out, save};
+  hipLaunchKernelGGL(ta_attn_decode_fwd_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  MTAM_CHECK_LAUNCH("ta_attn_decode_fwd");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_ta_attn_decode_bwd(const float *d_out, const float *dec_in, const float *x,
+                                       const float *kv, int ld_kv, int k_off, int v_off,
+                                       const float *t_query, const float *t_keys, const int32_t *seq_len,
+                                       const float *wqt, const float *tparams, const float *ln_gamma,
+                                       const float *save, int B, int L, int H, int accumulate_dx,
+                                       float *d_dec_in, float *d_kv, float *d_x, float *d_qt_pre,
+                                       float *d_tparams_partial, float *d_ln_partial, void *stream) {
+  MTAM_CHECK_ARG(d_out && dec_in && x && kv && t_query && t_keys && seq_len && wqt && tparams && ln_gamma &&
+                     save && d_dec_in && d_kv && d_x && d_qt_pre && d_tparams_partial && d_ln_partial,
+                 "ta_attn_decode_bwd: null argument");
+  int rc = check_attn_common("ta_attn_decode_bwd", B, L, H, ld_kv, k_off, v_off, kv, x);
+  if (rc) return rc;
+  MTAM_CHECK_ARG(mtam_aligned16(d_kv) && mtam_aligned16(d_x), "ta_attn_decode_bwd: d_kv and d_x must be 16-byte aligned");
+  BwdArgs a{d_out, dec_in, x, kv, ld_kv, k_off, v_off, t_query, t_keys, seq_len, wqt, tparams, ln_gamma,
+            save, B, L, H, accumulate_dx, d_dec_in, d_kv, d_x, d_qt_pre, d_tparams_partial, d_ln_partial};
+  hipLaunchKernelGGL(ta_attn_decode_bwd_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  MTAM_CHECK_LAUNCH("ta_attn_decode_bwd");
+  return MTAM_OK;
+}

@@ -1,0 +1,340 @@
+// Time-aware GRU (TimeAwareGRUCell_decay_new under dynamic_rnn) forward and
+// backward-through-time: Model/Modules/time_aware_rnn.py:186-269,
+// Model/Modules/gru.py:69-77, plus gather_indexes(seq_len - 2)
+// (Model/Modules/net_utils.py:82-92, Model/MTAMRec_model.py:75-79).
+//
+// The recurrence is a chain of seq_len-1 dependent steps per sample, each a
+// [1,128]x[128,256] and a [1,128]x[128,128] product: latency-bound, not
+// bandwidth- or MFMA-bound.  The input halves of both products are hoisted out
+// of the loop into one GEMM (xproj); what stays serial is the recurrent half.
+// One 512-thread workgroup (8 waves) owns one sample and keeps the recurrent
+// weights (128 x 384 fp32 = 196 KB, more than the 160 KB LDS) in registers for
+// the whole sequence: wave w owns k in [16w, 16w+16) and every output column
+// (4 gate + 2 candidate columns per lane, 96 VGPRs).  Per step a wave reads its
+// 16 h values from LDS as 4 broadcast ds_read_b128, multiplies, and the 8
+// k-slices are summed through LDS.  No weight byte is re-read per step.
+#include "common.h"
+
+namespace {
+
+constexpr int D = MTAM_D;
+constexpr int NW = 8;  // waves per workgroup
+
+// tvec rows
+enum { KW1 = 0, KB1, HW1, W1, B1, KW2, W12, B12, NTV };
+
+struct FwdArgs {
+  const float *xproj, *x, *timelast;
+  const int32_t *seq_len;
+  const float *wh_g, *wh_c, *tvec;
+  int B, L;
+  float *hs, *short_out, *save;
+};
+
+__global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float h_s[D];
+  __shared__ __attribute__((aligned(16))) float rh_s[D];
+  __shared__ float u_s[D];
+  __shared__ float pg[NW][2 * D];
+  __shared__ float pc[NW][D];
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int steps = min(max(p.seq_len[b] - 1, 0), p.L);
+  const size_t row0 = (size_t)b * p.L;
+
+  // recurrent weights -> registers (coalesced: lanes run along the output column)
+  float wg[16][4], wc[16][2];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wg[kk][j] = p.wh_g[(size_t)(16 * w + kk) * (2 * D) + lane + 64 * j];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wc[kk][j] = p.wh_c[(size_t)(16 * w + kk) * D + lane + 64 * j];
+  }
+  float tv[NTV];
+#pragma unroll
+  for (int i = 0; i < NTV; ++i) tv[i] = (tid < D) ? p.tvec[i * D + tid] : 0.f;
+
+  if (tid < D) h_s[tid] = 0.f;
+
+  // software prefetch of step t's inputs (independent of the recurrence)
+  float n_xg = 0.f, n_xc = 0.f, n_x = 0.f, n_dl = 0.f;
+  auto prefetch = [&](int t) {
+    const size_t r = row0 + t;
+    if (tid < 2 * D) n_xg = p.xproj[r * (3 * D) + tid];
+    if (tid < D) {
+      n_xc = p.xproj[r * (3 * D) + 2 * D + tid];
+      n_x = p.x[r * D + tid];
+      n_dl = p.timelast[r];
+    }
+  };
+  if (steps > 0) prefetch(0);
+  __syncthreads();
+
+  for (int t = 0; t < steps; ++t) {
+    const float xg = n_xg, xc = n_xc, xt = n_x, dl = n_dl;
+    if (t + 1 < steps) prefetch(t + 1);
+
+    // phase 1: gate pre-activations, recurrent half
+    {
+      float hv[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(&h_s[16 * w + 4 * q]);
+        hv[4 * q] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
+      }
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(hv[kk], wg[kk][j], acc[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pg[w][lane + 64 * j] = acc[j];
+    }
+    __syncthreads();
+    float r_keep = 0.f;
+    if (tid < 2 * D) {
+      float g = xg;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) g += pg[q][tid];
+      const float s = sigmoidf_(g);
+      if (tid < D) {
+        r_keep = s;
+        rh_s[tid] = s * h_s[tid];
+      } else {
+        u_s[tid - D] = s;
+      }
+    }
+    __syncthreads();
+    // phase 2: candidate pre-activation, recurrent half on r*h
+    {
+      float rv[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(&rh_s[16 * w + 4 * q]);
+        rv[4 * q] = v.x; rv[4 * q + 1] = v.y; rv[4 * q + 2] = v.z; rv[4 * q + 3] = v.w;
+      }
+      float acc[2] = {0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = fmaf(rv[kk], wc[kk][j], acc[j]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pc[w][lane + 64 * j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < D) {
+      float cp = xc;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) cp += pc[q][tid];
+      const float c = tanhf(cp);
+      const float h = h_s[tid];
+      const float tw = fmaxf(xt * tv[KW1] + tv[KB1] + h * tv[HW1], 0.f);
+      const float ts = fmaxf(tv[W1] * dl + tv[B1], 0.f);
+      const float T = sigmoidf_(tv[KW2] * tw + tv[W12] * ts + tv[B12]);
+      const float u = u_s[tid];
+      const float hn = u * h + (1.f - u) * c * T;
+      const size_t r = row0 + t;
+      p.hs[r * D + tid] = hn;
+      if (p.save) {
+        float *sv = p.save + r * (5 * D) + tid;
+        sv[0] = r_keep; sv[D] = u; sv[2 * D] = c; sv[3 * D] = T; sv[4 * D] = h;
+      }
+      h_s[tid] = hn;
+    }
+    __syncthreads();
+  }
+
+  if (tid < D) {
+    p.short_out[(size_t)b * D + tid] = (steps > 0) ? h_s[tid] : 0.f;
+    for (int t = steps; t < p.L; ++t) p.hs[(row0 + t) * D + tid] = 0.f;   // dynamic_rnn zero-fills dead steps
+  }
+}
+
+struct BwdArgs {
+  const float *d_short, *x, *timelast;
+  const int32_t *seq_len;
+  const float *wh_g, *wh_c, *tvec, *save;
+  int B, L;
+  float *d_xproj, *rh, *d_x, *d_tvec_partial;
+};
+
+__global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float dc_s[D];
+  __shared__ __attribute__((aligned(16))) float dg_s[2 * D];
+  __shared__ float pA[NW][D];
+  __shared__ float pB[NW][D];
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int steps = min(max(p.seq_len[b] - 1, 0), p.L);
+  const size_t row0 = (size_t)b * p.L;
+
+  // transposed recurrent weights -> registers: lane owns outputs k = lane, lane + 64;
+  // wave w owns n in [16w,16w+16) of the candidate kernel and [32w,32w+32) of the gate kernel.
+  float wcT[16][2], wgT[32][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = lane + 64 * j;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(&p.wh_c[(size_t)k * D + 16 * w + 4 * q]);
+      wcT[4 * q][j] = v.x; wcT[4 * q + 1][j] = v.y; wcT[4 * q + 2][j] = v.z; wcT[4 * q + 3][j] = v.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(&p.wh_g[(size_t)k * (2 * D) + 32 * w + 4 * q]);
+      wgT[4 * q][j] = v.x; wgT[4 * q + 1][j] = v.y; wgT[4 * q + 2][j] = v.z; wgT[4 * q + 3][j] = v.w;
+    }
+  }
+  float tv[NTV], gtv[NTV];
+#pragma unroll
+  for (int i = 0; i < NTV; ++i) {
+    tv[i] = (tid < D) ? p.tvec[i * D + tid] : 0.f;
+    gtv[i] = 0.f;
+  }
+
+  // zero-fill the dead steps of the outputs
+  for (int t = steps; t < p.L; ++t) {
+    const size_t r = row0 + t;
+    if (tid < 3 * D) p.d_xproj[r * (3 * D) + tid] = 0.f;
+    if (tid < D) p.rh[r * D + tid] = 0.f;
+  }
+
+  float dh = (tid < D && steps > 0) ? p.d_short[(size_t)b * D + tid] : 0.f;
+
+  float n_r = 0.f, n_u = 0.f, n_c = 0.f, n_T = 0.f, n_hp = 0.f, n_x = 0.f, n_dl = 0.f;
+  auto prefetch = [&](int t) {
+    if (tid < D) {
+      const size_t r = row0 + t;
+      const float *sv = p.save + r * (5 * D) + tid;
+      n_r = sv[0]; n_u = sv[D]; n_c = sv[2 * D]; n_T = sv[3 * D]; n_hp = sv[4 * D];
+      n_x = p.x[r * D + tid];
+      n_dl = p.timelast[r];
+    }
+  };
+  if (steps > 0) prefetch(steps - 1);
+
+  for (int t = steps - 1; t >= 0; --t) {
+    const float r_ = n_r, u = n_u, c = n_c, T = n_T, hp = n_hp, xt = n_x, dl = n_dl;
+    if (t > 0) prefetch(t - 1);
+    const size_t row = row0 + t;
+    float du = 0.f, dhp = 0.f, dcpre = 0.f;
+    if (tid < D) {
+      du = dh * (hp - c * T);
+      const float dc = dh * (1.f - u) * T;
+      const float dT = dh * (1.f - u) * c;
+      dhp = dh * u;
+      dcpre = dc * (1.f - c * c);
+      dc_s[tid] = dcpre;
+      // time gate T = sigmoid(kw2*tw + w12*ts + b12), tw = relu(x*kw1 + kb1 + h*hw1), ts = relu(w1*dl + b1)
+      const float twp = xt * tv[KW1] + tv[KB1] + hp * tv[HW1];
+      const float tsp = tv[W1] * dl + tv[B1];
+      const float tw = fmaxf(twp, 0.f), ts = fmaxf(tsp, 0.f);
+      const float dTp = dT * T * (1.f - T);
+      gtv[KW2] += dTp * tw;
+      gtv[W12] += dTp * ts;
+      gtv[B12] += dTp;
+      const float dtw = (twp > 0.f) ? dTp * tv[KW2] : 0.f;
+      const float dts = (tsp > 0.f) ? dTp * tv[W12] : 0.f;
+      gtv[KW1] += dtw * xt;
+      gtv[KB1] += dtw;
+      gtv[HW1] += dtw * hp;
+      gtv[W1] += dts * dl;
+      gtv[B1] += dts;
+      p.d_x[row * D + tid] += dtw * tv[KW1];
+      dhp += dtw * tv[HW1];
+    }
+    __syncthreads();
+    // phase A: d(r*h) = dcpre . Wc_h^T
+    {
+      float dv[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(&dc_s[16 * w + 4 * q]);
+        dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
+      }
+      float acc[2] = {0.f, 0.f};
+#pragma unroll
+      for (int nn = 0; nn < 16; ++nn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = fmaf(dv[nn], wcT[nn][j], acc[j]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pA[w][lane + 64 * j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < D) {
+      float drh = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) drh += pA[q][tid];
+      const float dr = drh * hp;
+      dhp += drh * r_;
+      const float dgr = dr * r_ * (1.f - r_);
+      const float dgu = du * u * (1.f - u);
+      dg_s[tid] = dgr;
+      dg_s[D + tid] = dgu;
+      float *dx = p.d_xproj + row * (3 * D) + tid;
+      dx[0] = dgr; dx[D] = dgu; dx[2 * D] = dcpre;
+      p.rh[row * D + tid] = r_ * hp;
+    }
+    __syncthreads();
+    // phase B: dh_prev += dgpre . Wg_h^T
+    {
+      float dv[32];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(&dg_s[32 * w + 4 * q]);
+        dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
+      }
+      float acc[2] = {0.f, 0.f};
+#pragma unroll
+      for (int nn = 0; nn < 32; ++nn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = fmaf(dv[nn], wgT[nn][j], acc[j]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pB[w][lane + 64 * j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < D) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) dhp += pB[q][tid];
+      dh = dhp;
+    }
+  }
+
+  if (tid < D) {
+#pragma unroll
+    for (int i = 0; i < NTV; ++i) p.d_tvec_partial[((size_t)b * NTV + i) * D + tid] = gtv[i];
+  }
+}
+
+}  // namespace
+
+extern "C" int mtam_tagru_fwd(const float *xproj, const float *x, const float *timelast,
+                              const int32_t *seq_len, const float *wh_g, const float *wh_c,
+                              const float *tvec, int B, int L, float *hs, float *short_out,
+                              float *save, void *stream) {
+  MTAM_CHECK_ARG(B > 0 && L > 0, "tagru_fwd: B and L must be positive");
+  MTAM_CHECK_ARG(xproj && x && timelast && seq_len && wh_g && wh_c && tvec && hs && short_out,
+                 "tagru_fwd: null argument");
+  FwdArgs a{xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save};
+  hipLaunchKernelGGL(tagru_fwd_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), a);
+  MTAM_CHECK_LAUNCH("tagru_fwd");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_tagru_bwd(const float *d_short, const float *x, const float *timelast,
+                              const int32_t *seq_len, const float *wh_g, const float *wh_c,
+                              const float *tvec, const float *save, int B, int L, float *d_xproj,
+                              float *rh, float *d_x, float *d_tvec_partial, void *stream) {
+  MTAM_CHECK_ARG(B > 0 && L > 0, "tagru_bwd: B and L must be positive");
+  MTAM_CHECK_ARG(d_short && x && timelast && seq_len && wh_g && wh_c && tvec && save && d_xproj && rh &&
+                     d_x && d_tvec_partial,
+                 "tagru_bwd: null argument");
+  MTAM_CHECK_ARG(mtam_aligned16(wh_g) && mtam_aligned16(wh_c), "tagru_bwd: weights must be 16-byte aligned");
+  BwdArgs a{d_short, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xproj, rh, d_x, d_tvec_partial};
+  hipLaunchKernelGGL(tagru_bwd_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), a);
+  MTAM_CHECK_LAUNCH("tagru_bwd");
+  return MTAM_OK;
+}

@@ -1,0 +1,192 @@
+"""Torch-tensor front end of the C ABI: pointer/shape plumbing only.
+
+Every function takes device tensors, checks dtype/contiguity, and calls the
+matching ``mtam_*`` entry point on torch's current HIP stream.  PyTorch is used
+for device memory and streams; all arithmetic happens in libmtam_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+EPI_STORE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_ADD, EPI_ACCUM, EPI_ACCUM_MASK, EPI_ATOMIC = range(7)
+D = 128
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.MtamHipError("expected a device tensor")
+    if t.dtype != dtype:
+        raise _lib.MtamHipError("expected dtype %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.MtamHipError("expected a contiguous tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _pi(t):
+    return _p(t, torch.int32)
+
+
+def gemm(a, b, c, trans_a=False, trans_b=False, epilogue=EPI_STORE, bias=None, aux_in=None,
+         aux_out=None, split_k=1, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, ld_aux=None):
+    """C = op(A) op(B) (+ epilogue).  2-D tensors; leading dimensions default to row lengths.
+    Sub-matrix views are expressed with explicit M/N/K/ld* over a base tensor slice
+    obtained by ``tensor.view(-1)[offset:]``."""
+    lib = _lib.load()
+    if lda is None:
+        lda = a.shape[-1]
+    if ldb is None:
+        ldb = b.shape[-1]
+    if ldc is None:
+        ldc = c.shape[-1]
+    if M is None:
+        M = a.shape[1] if trans_a else a.shape[0]
+    if K is None:
+        K = a.shape[0] if trans_a else a.shape[1]
+    if N is None:
+        N = b.shape[0] if trans_b else b.shape[1]
+    if ld_aux is None:
+        ld_aux = aux_in.shape[-1] if aux_in is not None else 0
+    rc = lib.mtam_gemm_f32(int(trans_a), int(trans_b), M, N, K, _p(a), lda, _p(b), ldb, _p(c), ldc,
+                           epilogue, _p(bias), _p(aux_in), _p(aux_out), ld_aux, split_k, _stream())
+    _lib.check(rc, "mtam_gemm_f32")
+
+
+def colsum_atomic(x, out, rows=None, cols=None, ld=None):
+    lib = _lib.load()
+    rows = x.shape[0] if rows is None else rows
+    cols = x.shape[1] if cols is None else cols
+    ld = x.shape[-1] if ld is None else ld
+    _lib.check(lib.mtam_colsum_atomic(_p(x), rows, cols, ld, _p(out), _stream()), "mtam_colsum_atomic")
+
+
+def emb_gather_partials(B, L):
+    return _lib.load().mtam_emb_gather_partials(B, L)
+
+
+def emb_gather_fwd(item_table, cat_table, pos_table, user_table, item_ids, cat_ids, pos_ids, user_ids,
+                   B, L, with_user, ic_out, pos_out, user_out, l2_partial):
+    lib = _lib.load()
+    rc = lib.mtam_emb_gather_fwd(_p(item_table), item_table.shape[0], _p(cat_table), cat_table.shape[0],
+                                 _p(pos_table), pos_table.shape[0], _p(user_table), user_table.shape[0],
+                                 _pi(item_ids), _pi(cat_ids), _pi(pos_ids), _pi(user_ids), B, L,
+                                 int(with_user), _p(ic_out), _p(pos_out), _p(user_out), _p(l2_partial),
+                                 _stream())
+    _lib.check(rc, "mtam_emb_gather_fwd")
+
+
+def emb_scatter_partials(B, L):
+    return _lib.load().mtam_emb_scatter_partials(B, L)
+
+
+def emb_scatter_add_bwd(d_ic, d_pos, ic, pos, user, item_ids, cat_ids, pos_ids, user_ids, seq_len, B, L,
+                        reg, with_user, g_item, g_cat, g_pos, g_user, slot_sq_partial):
+    lib = _lib.load()
+    rc = lib.mtam_emb_scatter_add_bwd(_p(d_ic), _p(d_pos), _p(ic), _p(pos), _p(user), _pi(item_ids),
+                                      _pi(cat_ids), _pi(pos_ids), _pi(user_ids), _pi(seq_len), B, L,
+                                      float(reg), int(with_user), _p(g_item), g_item.shape[0], _p(g_cat),
+                                      g_cat.shape[0], _p(g_pos), g_pos.shape[0], _p(g_user),
+                                      g_user.shape[0], _p(slot_sq_partial), _stream())
+    _lib.check(rc, "mtam_emb_scatter_add_bwd")
+
+
+def tagru_fwd(xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save):
+    lib = _lib.load()
+    rc = lib.mtam_tagru_fwd(_p(xproj), _p(x), _p(timelast), _pi(seq_len), _p(wh_g), _p(wh_c), _p(tvec),
+                            B, L, _p(hs), _p(short_out), _p(save), _stream())
+    _lib.check(rc, "mtam_tagru_fwd")
+
+
+def tagru_bwd(d_short, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xproj, rh, d_x,
+              d_tvec_partial):
+    lib = _lib.load()
+    rc = lib.mtam_tagru_bwd(_p(d_short), _p(x), _p(timelast), _pi(seq_len), _p(wh_g), _p(wh_c), _p(tvec),
+                            _p(save), B, L, _p(d_xproj), _p(rh), _p(d_x), _p(d_tvec_partial), _stream())
+    _lib.check(rc, "mtam_tagru_bwd")
+
+
+def ta_attn_decode_save_floats(L, H):
+    return _lib.load().mtam_ta_attn_decode_save_floats(L, H)
+
+
+def ta_attn_decode_fwd(dec_in, x, kv, ld_kv, k_off, v_off, t_query, t_keys, seq_len, wqt, bq, tparams,
+                       ln_beta, ln_gamma, B, L, H, dec_out, save):
+    lib = _lib.load()
+    rc = lib.mtam_ta_attn_decode_fwd(_p(dec_in), _p(x), _p(kv), ld_kv, k_off, v_off, _p(t_query),
+                                     _p(t_keys), _pi(seq_len), _p(wqt), _p(bq), _p(tparams), _p(ln_beta),
+                                     _p(ln_gamma), B, L, H, _p(dec_out), _p(save), _stream())
+    _lib.check(rc, "mtam_ta_attn_decode_fwd")
+
+
+def ta_attn_decode_bwd(d_out, dec_in, x, kv, ld_kv, k_off, v_off, t_query, t_keys, seq_len, wqt, tparams,
+                       ln_gamma, save, B, L, H, accumulate_dx, d_dec_in, d_kv, d_x, d_qt_pre,
+                       d_tparams_partial, d_ln_partial):
+    lib = _lib.load()
+    rc = lib.mtam_ta_attn_decode_bwd(_p(d_out), _p(dec_in), _p(x), _p(kv), ld_kv, k_off, v_off,
+                                     _p(t_query), _p(t_keys), _pi(seq_len), _p(wqt), _p(tparams),
+                                     _p(ln_gamma), _p(save), B, L, H, int(accumulate_dx), _p(d_dec_in),
+                                     _p(d_kv), _p(d_x), _p(d_qt_pre), _p(d_tparams_partial),
+                                     _p(d_ln_partial), _stream())
+    _lib.check(rc, "mtam_ta_attn_decode_bwd")
+
+
+def layer_norm_fwd(x, beta, gamma, eps, rows, y, save):
+    lib = _lib.load()
+    _lib.check(lib.mtam_layer_norm_fwd(_p(x), _p(beta), _p(gamma), float(eps), rows, _p(y), _p(save),
+                                       _stream()), "mtam_layer_norm_fwd")
+
+
+def layer_norm_bwd(d_y, gamma, save, rows, d_x, d_bg):
+    lib = _lib.load()
+    _lib.check(lib.mtam_layer_norm_bwd(_p(d_y), _p(gamma), _p(save), rows, _p(d_x), _p(d_bg), _stream()),
+               "mtam_layer_norm_bwd")
+
+
+def softmax_ce_partials(B, V):
+    return _lib.load().mtam_softmax_ce_partials(B, V)
+
+
+def softmax_ce(logits, ld, target, B, V, grad_scale, lse, ce, d_logits, partial):
+    lib = _lib.load()
+    rc = lib.mtam_softmax_ce(_p(logits), ld, _pi(target), B, V, float(grad_scale), _p(lse), _p(ce),
+                             _p(d_logits), _p(partial), _stream())
+    _lib.check(rc, "mtam_softmax_ce")
+
+
+def loss_reduce(l2_partial, n_l2, ce, B, reg, ce_scale, loss):
+    lib = _lib.load()
+    _lib.check(lib.mtam_loss_reduce(_p(l2_partial), n_l2, _p(ce), B, float(reg), float(ce_scale),
+                                    _p(loss), _stream()), "mtam_loss_reduce")
+
+
+def topk(scores, ld, rows, V, k, idx_out, val_out=None):
+    lib = _lib.load()
+    _lib.check(lib.mtam_topk(_p(scores), ld, rows, V, k, _pi(idx_out), _p(val_out), _stream()), "mtam_topk")
+
+
+def sqnorm_blocks(n):
+    return _lib.load().mtam_sqnorm_blocks(n)
+
+
+def sqnorm_partial(g, n, partial):
+    lib = _lib.load()
+    _lib.check(lib.mtam_sqnorm_partial(_p(g), n, _p(partial), _stream()), "mtam_sqnorm_partial")
+
+
+def clip_scale(partials, n_partials, clip_norm, scale):
+    lib = _lib.load()
+    _lib.check(lib.mtam_clip_scale(_p(partials), n_partials, float(clip_norm), _p(scale), _stream()),
+               "mtam_clip_scale")
+
+
+def adam(p, m, v, g, n, scale, hyper, sparse_form):
+    lib = _lib.load()
+    _lib.check(lib.mtam_adam(_p(p), _p(m), _p(v), _p(g), n, _p(scale), _p(hyper), int(sparse_form),
+                             _stream()), "mtam_adam")

@@ -1,0 +1,331 @@
+"""CPU oracle of the time-aware training path.  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors
+ and its arithmetic lives in tensorflow==1.14.0 / keras, which
+are not installed here -- this file restates the reference's
+graph op for op and is pinned only by (1) agreement with the independent numpy
+fp64 restatement in ``numpy_ref.py``, (2) hand-derived known-answer cases and
+(3) finite-difference gradient checks (tests/test_oracle.py).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline
+leg may import this module.  The product path never does.
+
+Deliberately unfused and written with plain torch-CPU ops, one per TF op, so
+that timing it is a fair "CPU restatement of the TF1.14 graph" baseline
+(BASELINE.md section 3).  Each function cites the reference lines it follows.
+TF 1.14 behaviours not visible in the tree are marked [TF1.14]
+(SURVEY.md Appendix D).
+"""
+import math
+
+import numpy as np
+import torch
+
+from mtamrecommender_amd.Model.variables import GRU_SCOPE, TIME_GATE
+
+MASK_VALUE = float(-2 ** 32 + 1)      # time_aware_attention.py:392
+
+
+def to_torch(arrays, dtype):
+    out = {}
+    for k, v in arrays.items():
+        t = torch.from_numpy(np.ascontiguousarray(v))
+        out[k] = t.to(dtype) if t.is_floating_point() else t
+    return out
+
+
+def feed_to_torch(feed, dtype):
+    out = {}
+    for k, v in feed.items():
+        t = torch.from_numpy(np.ascontiguousarray(v))
+        out[k] = t.to(dtype) if t.is_floating_point() else t.long()
+    return out
+
+
+# ---------------------------------------------------------------- embedding
+def get_embedding(w, feed):
+    """Embedding/Behavior_embedding_time_aware_attention.py:62-114."""
+    user = w["embedding_layer/user"][feed["user_id"]]
+    item = w["embedding_layer/item_gather"][feed["item_list"]]
+    cat = w["embedding_layer/category"][feed["category_list"]]
+    pos = w["embedding_layer/position"][feed["position_list"]]
+    concat = torch.cat([item, cat], dim=2)
+    dense = torch.relu(torch.matmul(concat, w["position_embedding/dense4emb/kernel"]))
+    dense = dense + pos
+    return user, dense, item, cat, pos
+
+
+# ---------------------------------------------------------------- GRU
+def time_aware_gru(w, x, timelast, seq_len_m1):
+    """dynamic_rnn(TimeAwareGRUCell_decay_new): Model/Modules/gru.py:69-77,
+    Model/Modules/time_aware_rnn.py:186-269.  Outputs past ``sequence_length``
+    are zero and the state is carried through [TF1.14]."""
+    B, L, D = x.shape
+    p = lambda n: w[GRU_SCOPE + n]
+    h = torch.zeros(B, D, dtype=x.dtype)
+    outs = []
+    for t in range(L):
+        xt = x[:, t, :]
+        dlast = timelast[:, t:t + 1]
+        tw = torch.relu(xt * p("_time_kernel_w1") + p("_time_kernel_b1") + h * p("_time_history_w1"))
+        ts = torch.relu(p("_time_w1") * dlast + p("_time_b1"))
+        tgate = torch.sigmoid(p("_time_kernel_w2") * tw + p("_time_w12") * ts + p("_time_b12"))
+        gates = torch.sigmoid(torch.matmul(torch.cat([xt, h], 1), p("gates/kernel")) + p("gates/bias"))
+        r, u = gates[:, :D], gates[:, D:]
+        c = torch.tanh(torch.matmul(torch.cat([xt, r * h], 1), p("candidate/kernel"))
+                       + p("candidate/bias"))
+        new_h = u * h + (1 - u) * c * tgate
+        live = (t < seq_len_m1).unsqueeze(1)
+        outs.append(torch.where(live, new_h, torch.zeros_like(new_h)))
+        h = torch.where(live, new_h, h)
+    return torch.stack(outs, dim=1)
+
+
+def gather_indexes(seq, positions):
+    """Model/Modules/net_utils.py:82-92 (flat gather at b*L + pos)."""
+    B, L, D = seq.shape
+    flat = seq.reshape(B * L, D)
+    return flat[torch.arange(B) * L + positions]
+
+
+# ---------------------------------------------------------------- attention
+def normalize(x, beta, gamma, eps=1e-8):
+    """Time_Aware_Attention.normalize, time_aware_attention.py:7-34."""
+    mean = x.mean(dim=-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
+    return gamma * ((x - mean) / ((var + eps) ** 0.5)) + beta
+
+
+def layer_norm(x, beta, gamma, eps=1e-12):
+    """tf.contrib.layers.layer_norm via nn.batch_normalization [TF1.14]
+    (net_utils.py:229-232): x*inv + (beta - mean*inv), inv = rsqrt(var+eps)*gamma."""
+    mean = x.mean(dim=-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
+    inv = torch.rsqrt(var + eps) * gamma
+    return x * inv + (beta - mean * inv)
+
+
+def time_aware_multihead_attention(w, scope, inner, q, k, key_len, query_len, tq, tk, num_heads):
+    """time_aware_attention.py:215-456.  q:[B,Tq,D] k:[B,Tk,D] tq:[B,Tq] tk:[B,Tk]."""
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    g = lambda n: w[scope + n]
+    Q = torch.relu(torch.matmul(q, g("dense/kernel")) + g("dense/bias"))
+    K = torch.relu(torch.matmul(k, g("dense_1/kernel")) + g("dense_1/bias"))
+    V = torch.relu(torch.matmul(k, g("dense_2/kernel")) + g("dense_2/bias"))
+    s = scope + inner + "/"
+    tqk = torch.tanh(torch.matmul(torch.matmul(q, w[s + "_time_input_w"]), k.transpose(1, 2)))
+    decay = torch.log(torch.abs(tq.unsqueeze(2) - tk.unsqueeze(1)) + 1)
+    decay = torch.tanh(decay * w[s + "_time_input_w1"] + w[s + "_time_input_b1"])
+    gate = w[s + "time_output_w1"] * decay + w[s + "time_output_w2"] * tqk + w[s + "time_output_b"]
+    d = D // num_heads
+    Q_ = torch.cat(torch.split(Q, d, dim=2), dim=0)
+    K_ = torch.cat(torch.split(K, d, dim=2), dim=0)
+    V_ = torch.cat(torch.split(V, d, dim=2), dim=0)
+    gate_ = torch.cat([gate] * num_heads, dim=0)
+    out = torch.matmul(Q_, K_.transpose(1, 2))
+    out = out * torch.sigmoid(gate_)
+    out = out / (d ** 0.5)
+    key_mask = (torch.arange(Tk).unsqueeze(0) < key_len.unsqueeze(1))           # [B,Tk]
+    key_mask = key_mask.repeat(num_heads, 1).unsqueeze(1).expand(-1, Tq, -1)
+    out = torch.where(key_mask, out, torch.full_like(out, MASK_VALUE))
+    out = torch.softmax(out, dim=-1)
+    q_mask = (torch.arange(Tq).unsqueeze(0) < query_len.unsqueeze(1)).to(out.dtype)
+    out = out * q_mask.repeat(num_heads, 1).unsqueeze(2)
+    att = out
+    out = torch.matmul(out, V_)
+    out = torch.cat(torch.split(out, B, dim=0), dim=2)
+    out = out + q
+    out = normalize(out, w[s + "ln/Variable"], w[s + "ln/Variable_1"])
+    return out, att
+
+
+def vanilla_attention(w, enc, dec, key_len, tq, tk, num_heads, num_blocks):
+    """Decoder stack, time_aware_attention.py:524-556 (enc fixed, dec fed forward)."""
+    B, _, D = dec.shape
+    qlen = torch.ones(B, dtype=torch.long)
+    for i in range(num_blocks):
+        dec, _ = time_aware_multihead_attention(
+            w, "NextItemDecoder/decoder/num_blocks_%d/" % i, "vanilla_attention",
+            dec, enc, key_len, qlen, tq, tk, num_heads)
+    return dec.reshape(-1, D)
+
+
+def self_attention(w, enc, seq_len, t, num_heads, num_blocks):
+    """Encoder stack, time_aware_attention.py:459-490."""
+    for i in range(num_blocks):
+        enc, _ = time_aware_multihead_attention(
+            w, "UserHistoryEncoder/encoder/num_blocks_%d/" % i, "self_attention",
+            enc, enc, seq_len, seq_len, t, t, num_heads)
+    return enc
+
+
+# ---------------------------------------------------------------- models
+def forward(model, w, feed, num_heads, num_blocks, regulation_rate, global_batch=None):
+    """MTAM.build_model (Model/MTAMRec_model.py:61-92) or
+    Time_Aware_self_Attention_model.build_model (Model/PISTRec_model.py:38-74),
+    followed by base_model.output (Model/base_model.py:300-328).
+
+    ``w`` holds the item table twice (``item_gather`` / ``item_score``) so that
+    the gather gradient and the dense scoring gradient stay separable, as TF's
+    IndexedSlices aggregation keeps them.
+    ``global_batch``: mean divisor for data-parallel shards (default: local B).
+    """
+    user, x, item, cat, pos = get_embedding(w, feed)
+    sl = feed["seq_length"]
+    B = x.shape[0]
+    if model == "MTAM":
+        hs = time_aware_gru(w, x, feed["timelast_list"], sl - 1)
+        short = gather_indexes(hs, sl - 2)
+        dec = vanilla_attention(w, x, short.unsqueeze(1), sl, feed["target_item_time"].unsqueeze(1),
+                                feed["time_list"], num_heads, num_blocks)
+        pred = layer_norm(dec, w["NextItemDecoder/LayerNorm/beta"], w["NextItemDecoder/LayerNorm/gamma"])
+        l2 = 0.5 * (item ** 2).sum() + 0.5 * (cat ** 2).sum() + 0.5 * (pos ** 2).sum() \
+            + 0.5 * (user ** 2).sum()
+    else:
+        enc = self_attention(w, x, sl, feed["time_list"], num_heads, num_blocks)
+        long_term = gather_indexes(enc, sl - 1)
+        pred = layer_norm(long_term, w["UserHistoryEncoder/LayerNorm/beta"],
+                          w["UserHistoryEncoder/LayerNorm/gamma"])
+        l2 = 0.5 * (item ** 2).sum() + 0.5 * (cat ** 2).sum() + 0.5 * (pos ** 2).sum()
+    logits = torch.matmul(pred, w["embedding_layer/item_score"].t())
+    log_probs = torch.log_softmax(logits, dim=-1)
+    one_hot = torch.nn.functional.one_hot(feed["target_item_id"], logits.shape[1]).to(logits.dtype)
+    ce = -(log_probs * one_hot).sum(dim=-1)
+    denom = B if global_batch is None else global_batch
+    loss = regulation_rate * l2 + ce.sum() / denom
+    return dict(pred=pred, logits=logits, ce=ce, l2=l2, loss=loss, x=x,
+                user=user, item=item, cat=cat, pos=pos,
+                hs=hs if model == "MTAM" else None)
+
+
+def split_item_table(arrays, dtype, requires_grad=True):
+    """numpy name->array  =>  torch leaves with the item table duplicated."""
+    w = {}
+    for k, v in arrays.items():
+        t = torch.from_numpy(np.ascontiguousarray(v)).to(dtype)
+        if k == "embedding_layer/item":
+            w["embedding_layer/item_gather"] = t.clone().requires_grad_(requires_grad)
+            w["embedding_layer/item_score"] = t.clone().requires_grad_(requires_grad)
+        else:
+            w[k] = t.clone().requires_grad_(requires_grad)
+    return w
+
+
+def loss_and_grads(model, arrays, feed, num_heads, num_blocks, regulation_rate, dtype=torch.float32,
+                   global_batch=None):
+    """tf.gradients(loss, trainable) -- Model/base_model.py:292.
+
+    Returns (out, grads, slot_sq) where grads[name] is the dense (summed)
+    gradient per variable (None for variables the loss does not reach) and
+    slot_sq is the sum over un-deduplicated IndexedSlices rows of ||row||^2
+    for the four tables (what tf.global_norm sees, App D-5).
+    """
+    w = split_item_table(arrays, dtype)
+    f = feed_to_torch(feed, dtype)
+    out = forward(model, w, f, num_heads, num_blocks, regulation_rate, global_batch)
+    for key in ("user", "item", "cat", "pos"):
+        out[key].retain_grad()
+    out["loss"].backward()
+    grads = {}
+    for k, t in w.items():
+        if k in ("embedding_layer/item_gather", "embedding_layer/item_score"):
+            continue
+        grads[k] = None if t.grad is None else t.grad.detach().numpy()
+    grads["embedding_layer/item"] = (w["embedding_layer/item_gather"].grad
+                                     + w["embedding_layer/item_score"].grad).detach().numpy()
+    slot_sq = {}
+    for key in ("item", "cat", "pos"):
+        slot_sq[key] = float((out[key].grad.double() ** 2).sum())
+    slot_sq["user"] = float((out["user"].grad.double() ** 2).sum()) if out["user"].grad is not None else 0.0
+    slot_sq["item_dense"] = float((w["embedding_layer/item_score"].grad.double() ** 2).sum())
+    return out, grads, slot_sq
+
+
+def global_norm(grads, slot_sq, model, tf_compat=True):
+    """tf.global_norm over the gradient list (Model/base_model.py:294).
+    tf_compat: tables contribute the un-deduplicated IndexedSlices norm."""
+    total = 0.0
+    for k, g in grads.items():
+        if g is None:
+            continue
+        if tf_compat and k.startswith("embedding_layer/"):
+            continue
+        total += float((g.astype(np.float64) ** 2).sum())
+    if tf_compat:
+        total += slot_sq["item"] + slot_sq["item_dense"] + slot_sq["cat"] + slot_sq["pos"]
+        if model == "MTAM":
+            total += slot_sq["user"]
+    return math.sqrt(total)
+
+
+class AdamState(object):
+    """tf.train.AdamOptimizer state [TF1.14]: m, v per variable and the two
+    beta-power accumulators kept in float32."""
+
+    def __init__(self, arrays):
+        self.m = {k: np.zeros_like(v) for k, v in arrays.items()}
+        self.v = {k: np.zeros_like(v) for k, v in arrays.items()}
+        self.beta1_power = np.float32(0.9)
+        self.beta2_power = np.float32(0.999)
+
+
+def train_step(model, arrays, state, feed, lr, num_heads, num_blocks, regulation_rate,
+               max_gradient_norm=1.0, tf_compat_norm=True, global_batch=None):
+    """One ``sess.run([loss, merged, train_op])`` (Model/base_model.py:150-167,290-297):
+    gradients -> clip_by_global_norm -> Adam.  Updates ``arrays``/``state`` in place."""
+    out, grads, slot_sq = loss_and_grads(model, arrays, feed, num_heads, num_blocks,
+                                         regulation_rate, torch.float32, global_batch)
+    norm = np.float32(global_norm(grads, slot_sq, model, tf_compat_norm))
+    c = np.float32(max_gradient_norm)
+    scale = c * min(np.float32(1.0) / norm, np.float32(1.0) / c)          # clip_by_global_norm [TF1.14]
+    b1, b2, eps = np.float32(0.9), np.float32(0.999), np.float32(1e-8)
+    lr32 = np.float32(lr)                                                 # lr placeholder is f64, cast to var dtype
+    lr_t = lr32 * np.sqrt(np.float32(1) - state.beta2_power) / (np.float32(1) - state.beta1_power)
+    for k, g in grads.items():
+        if g is None:
+            continue
+        g = (g * scale).astype(np.float32)
+        if k.startswith("embedding_layer/"):          # IndexedSlices path, _apply_sparse_shared
+            state.m[k] = state.m[k] * b1 + g * (np.float32(1) - b1)
+            state.v[k] = state.v[k] * b2 + (g * g) * (np.float32(1) - b2)
+        else:                                         # ApplyAdam kernel
+            state.m[k] = state.m[k] + (g - state.m[k]) * (np.float32(1) - b1)
+            state.v[k] = state.v[k] + (g * g - state.v[k]) * (np.float32(1) - b2)
+        arrays[k] = (arrays[k] - lr_t * state.m[k] / (np.sqrt(state.v[k]) + eps)).astype(np.float32)
+    state.beta1_power = np.float32(state.beta1_power * b1)
+    state.beta2_power = np.float32(state.beta2_power * b2)
+    return dict(loss=float(out["loss"]), ce_mean=float(out["ce"].mean()), l2=float(out["l2"]),
+                global_norm=float(norm), scale=float(scale), logits=out["logits"].detach().numpy(),
+                pred=out["pred"].detach().numpy(), grads=grads)
+
+
+# ---------------------------------------------------------------- eval
+def top_k(scores, k):
+    """tf.nn.top_k [TF1.14]: descending, equal values -> lower index first."""
+    scores = np.asarray(scores)
+    order = np.argsort(-scores, axis=1, kind="stable")
+    return order[:, :k].astype(np.int32)
+
+
+def calculate_topK(indices, targets):
+    """Model/base_model.py:215-242: recall and NDCG of one batch."""
+    hits = 0
+    ndcg = 0.0
+    for row, tgt in zip(indices, targets):
+        row = list(row)
+        if tgt in row:
+            hits += 1
+            ndcg += math.log(2) / math.log(row.index(tgt) + 2)
+    n = len(targets)
+    return hits / n, ndcg / n
+
+
+def metrics_topK(scores, targets, ks=(1, 5, 10, 30, 50)):
+    """Model/base_model.py:188-213 -> (hr1, ndcg1, hr5, ndcg5, ...)."""
+    out = []
+    top = top_k(scores, max(ks))
+    for k in ks:
+        hr, nd = calculate_topK(top[:, :k], targets)
+        out += [hr, nd]
+    return tuple(out)

@@ -1,0 +1,498 @@
+"""Per-kernel parity of libmtam_hip.so against CPU references (GPU box only).
+
+Each test feeds the same seeded inputs to one C-ABI entry point and to a float64
+restatement of the reference ops (the oracle where one exists, plain numpy
+otherwise).  Tolerances are stated per test; integer outputs are bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+D = 128
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rel_err(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    from mtamrecommender_amd import hip_ops
+    return hip_ops
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (100, 70, 45), (6400, 128, 256), (130, 384, 129)])
+def test_gemm_store(ops, ta, tb, M, N, K):
+    rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    Bm = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    ref = (A.T if ta else A).astype(np.float64) @ (Bm.T if tb else Bm).astype(np.float64)
+    C = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm(dev(A), dev(Bm), C, trans_a=bool(ta), trans_b=bool(tb))
+    assert rel_err(C.cpu().numpy(), ref) < 2e-6     # fp32 fma chain over K <= 256
+
+
+def test_gemm_is_ordered_fma_chain(ops):
+    """The fp32 MFMA result is bit-for-bit a k-ordered fmaf chain (what the
+    scoring contract for top-K relies on)."""
+    rng = np.random.default_rng(5)
+    M, N, K = 37, 50, 128
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bt = rng.standard_normal((N, K)).astype(np.float32)
+    C = torch.zeros((M, N), device="cuda")
+    ops.gemm(dev(A), dev(Bt), C, trans_b=True)
+    import oracle.c_oracle as co
+    ref = co.score_fma(A, Bt)
+    assert np.array_equal(C.cpu().numpy(), ref)
+
+
+def test_gemm_epilogues(ops):
+    rng = np.random.default_rng(11)
+    M, N, K = 150, 200, 96
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = rng.standard_normal((K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    aux = rng.standard_normal((M, N)).astype(np.float32)
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    acc = A.astype(np.float64) @ Bm.astype(np.float64)
+    tol = 2e-6
+
+    C = torch.zeros((M, N), device="cuda")
+    ops.gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_BIAS, bias=dev(bias))
+    assert rel_err(C.cpu().numpy(), acc + bias) < tol
+    ops.gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_BIAS_RELU, bias=dev(bias))
+    assert rel_err(C.cpu().numpy(), np.maximum(acc + bias, 0)) < tol
+    aux_out = torch.zeros((M, N), device="cuda")
+    ops.gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_RELU_ADD, aux_in=dev(aux), aux_out=aux_out)
+    assert rel_err(aux_out.cpu().numpy(), np.maximum(acc, 0)) < tol
+    assert rel_err(C.cpu().numpy(), np.maximum(acc, 0) + aux) < tol
+    C = dev(c0).clone()
+    ops.gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_ACCUM)
+    assert rel_err(C.cpu().numpy(), c0 + acc) < tol
+    C = dev(c0).clone()
+    ops.gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_ACCUM_MASK, aux_in=dev(aux), aux_out=aux_out)
+    assert rel_err(C.cpu().numpy(), c0 + acc) < tol
+    assert rel_err(aux_out.cpu().numpy(), np.where(aux > 0, c0 + acc, 0)) < tol
+
+
+@pytest.mark.parametrize("split", [1, 4, 25])
+def test_gemm_split_k_atomic(ops, split):
+    rng = np.random.default_rng(split)
+    K, M, N = 1850, 128, 384          # K = B*L of a short final batch (37 x 50)
+    A = rng.standard_normal((K, M)).astype(np.float32)
+    Bm = rng.standard_normal((K, N)).astype(np.float32)
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    C = dev(c0).clone()
+    ops.gemm(dev(A), dev(Bm), C, trans_a=True, epilogue=ops.EPI_ATOMIC, split_k=split)
+    ref = c0 + A.T.astype(np.float64) @ Bm.astype(np.float64)
+    assert rel_err(C.cpu().numpy(), ref) < 5e-6
+
+
+def test_gemm_submatrix_views(ops):
+    """Leading dimensions: B operand is a column block of a wider matrix."""
+    rng = np.random.default_rng(3)
+    R, wide = 200, 384
+    A = rng.standard_normal((R, D)).astype(np.float32)
+    G = rng.standard_normal((R, wide)).astype(np.float32)
+    Gd = dev(G)
+    C = torch.zeros((D, 256), device="cuda")
+    ops.gemm(dev(A), Gd.view(-1)[128:], C, trans_a=True, M=D, N=256, K=R, lda=D, ldb=wide, ldc=256)
+    ref = A.T.astype(np.float64) @ G[:, 128:384].astype(np.float64)
+    assert rel_err(C.cpu().numpy(), ref) < 2e-6
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from mtamrecommender_amd._lib import MtamHipError
+    a = torch.zeros((8, 8), device="cuda")
+    with pytest.raises(MtamHipError):
+        ops.gemm(a, a, a, epilogue=ops.EPI_BIAS)            # bias missing
+    with pytest.raises(MtamHipError):
+        ops.gemm(a, a, a, split_k=2)                        # split-K without atomic epilogue
+    with pytest.raises(MtamHipError):
+        ops.gemm(a.cpu(), a, a)                             # host tensor
+
+
+def test_colsum(ops):
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((777, 300)).astype(np.float32)
+    out = torch.ones(300, device="cuda")
+    ops.colsum_atomic(dev(x), out)
+    assert rel_err(out.cpu().numpy(), 1.0 + x.astype(np.float64).sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------- embedding
+def _emb_case(B, L, seed, rows=(97, 13, None, 31)):
+    rng = np.random.default_rng(seed)
+    vi, vc, vp, vu = rows[0], rows[1], (L + 3 if rows[2] is None else rows[2]), rows[3]
+    tabs = [rng.standard_normal((v, D)).astype(np.float32) for v in (vi, vc, vp, vu)]
+    sl = rng.integers(2, L + 1, size=B).astype(np.int32)
+    if B > 1:
+        sl[0] = L                                   # one sample without padding
+    ids = [np.zeros((B, L), np.int32) for _ in range(3)]
+    for b in range(B):
+        for t, v in zip(ids, (vi, vc, vp)):
+            t[b, :sl[b]] = rng.integers(0, v, size=sl[b])
+    uid = rng.integers(0, vu, size=B).astype(np.int32)
+    return tabs, ids, uid, sl
+
+
+@pytest.mark.parametrize("B,L", [(1, 2), (5, 7), (128, 50), (37, 50)])
+@pytest.mark.parametrize("with_user", [1, 0])
+def test_emb_gather(ops, B, L, with_user):
+    tabs, ids, uid, sl = _emb_case(B, L, B * 100 + L)
+    R = B * L
+    ic = torch.zeros((R, 2 * D), device="cuda")
+    pos = torch.zeros((R, D), device="cuda")
+    usr = torch.zeros((B, D), device="cuda")
+    npart = ops.emb_gather_partials(B, L)
+    part = torch.full((npart,), 123.0, device="cuda")
+    ops.emb_gather_fwd(dev(tabs[0]), dev(tabs[1]), dev(tabs[2]), dev(tabs[3]), dev(ids[0]), dev(ids[1]),
+                       dev(ids[2]), dev(uid), B, L, with_user, ic, pos, usr, part)
+    I, C, P, U = tabs[0][ids[0].ravel()], tabs[1][ids[1].ravel()], tabs[2][ids[2].ravel()], tabs[3][uid]
+    assert np.array_equal(ic.cpu().numpy(), np.concatenate([I, C], axis=1))     # row copy: bit exact
+    assert np.array_equal(pos.cpu().numpy(), P)
+    assert np.array_equal(usr.cpu().numpy(), U)
+    sq = sum(float((a.astype(np.float64) ** 2).sum()) for a in (I, C, P)) + \
+        (float((U.astype(np.float64) ** 2).sum()) if with_user else 0.0)
+    assert abs(float(part.double().sum()) - sq) / sq < 1e-6
+
+
+@pytest.mark.parametrize("B,L", [(1, 2), (5, 7), (128, 50)])
+@pytest.mark.parametrize("with_user", [1, 0])
+def test_emb_scatter_add(ops, B, L, with_user):
+    tabs, ids, uid, sl = _emb_case(B, L, B * 10 + L + 1)
+    rng = np.random.default_rng(B + L)
+    R = B * L
+    live = (np.arange(L)[None, :] < sl[:, None]).reshape(R, 1)
+    d_ic = (rng.standard_normal((R, 2 * D)) * live).astype(np.float32)          # zero at padded slots
+    d_pos = (rng.standard_normal((R, D)) * live).astype(np.float32)
+    I, C, P, U = tabs[0][ids[0].ravel()], tabs[1][ids[1].ravel()], tabs[2][ids[2].ravel()], tabs[3][uid]
+    ic = np.concatenate([I, C], axis=1)
+    reg = 0.37
+    g0 = [rng.standard_normal(t.shape).astype(np.float32) for t in tabs]        # pre-existing content
+    g = [dev(x).clone() for x in g0]
+    part = torch.full((ops.emb_scatter_partials(B, L),), 9.0, device="cuda")
+    ops.emb_scatter_add_bwd(dev(d_ic), dev(d_pos), dev(ic), dev(P), dev(U), dev(ids[0]), dev(ids[1]),
+                            dev(ids[2]), dev(uid), dev(sl), B, L, reg, with_user, g[0], g[1], g[2], g[3], part)
+    ref = [x.astype(np.float64) for x in g0]
+    ci = d_ic[:, :D].astype(np.float64) + reg * I
+    cc = d_ic[:, D:].astype(np.float64) + reg * C
+    cp = d_pos.astype(np.float64) + reg * P
+    np.add.at(ref[0], ids[0].ravel(), ci)
+    np.add.at(ref[1], ids[1].ravel(), cc)
+    np.add.at(ref[2], ids[2].ravel(), cp)
+    sq = float((ci ** 2).sum() + (cc ** 2).sum() + (cp ** 2).sum())
+    if with_user:
+        cu = reg * U.astype(np.float64)
+        np.add.at(ref[3], uid, cu)
+        sq += float((cu ** 2).sum())
+    for got, want in zip(g, ref):
+        assert rel_err(got.cpu().numpy(), want) < 1e-5     # float atomics: order-dependent rounding
+    assert abs(float(part.double().sum()) - sq) / sq < 1e-5
+
+
+# ------------------------------------------------------------------- GRU
+def _gru_weights(rng):
+    from mtamrecommender_amd.Model.variables import GRU_SCOPE, GRU_USED
+    w = {GRU_SCOPE + "gates/kernel": rng.uniform(-0.1, 0.1, (2 * D, 2 * D)),
+         GRU_SCOPE + "gates/bias": rng.uniform(0.5, 1.5, 2 * D),
+         GRU_SCOPE + "candidate/kernel": rng.uniform(-0.1, 0.1, (2 * D, D)),
+         GRU_SCOPE + "candidate/bias": rng.uniform(-0.2, 0.2, D)}
+    for n in GRU_USED:
+        w[GRU_SCOPE + n] = rng.uniform(-0.15, 0.15, D)
+    w[GRU_SCOPE + "_time_w1"] = rng.uniform(-0.01, 0.01, D)     # times are raw hours
+    return {k: v.astype(np.float32) for k, v in w.items()}
+
+
+def _gru_device_args(w):
+    from mtamrecommender_amd.Model.variables import GRU_SCOPE, GRU_USED
+    Wg, Wc = w[GRU_SCOPE + "gates/kernel"], w[GRU_SCOPE + "candidate/kernel"]
+    Wx = np.concatenate([Wg[:D], Wc[:D]], axis=1)                 # [D, 3D]
+    bx = np.concatenate([w[GRU_SCOPE + "gates/bias"], w[GRU_SCOPE + "candidate/bias"]])
+    tvec = np.stack([w[GRU_SCOPE + n] for n in GRU_USED])
+    return Wx, bx, np.ascontiguousarray(Wg[D:]), np.ascontiguousarray(Wc[D:]), tvec
+
+
+@pytest.mark.parametrize("B,L", [(3, 5), (16, 50), (128, 50)])
+def test_tagru_fwd_bwd(ops, B, L):
+    import oracle.mtam_oracle as O
+    rng = np.random.default_rng(B + 17 * L)
+    w = _gru_weights(rng)
+    x = rng.uniform(-0.5, 0.5, (B, L, D)).astype(np.float32)
+    tl = np.floor(rng.exponential(24.0, (B, L))).astype(np.float32)
+    sl = rng.integers(2, L + 1, size=B).astype(np.int32)
+    sl[0] = 2
+    sl[-1] = L
+    Wx, bx, whg, whc, tvec = _gru_device_args(w)
+    xproj = (x.reshape(-1, D).astype(np.float64) @ Wx + bx).astype(np.float32)
+    R = B * L
+    hs = torch.full((R, D), 5.0, device="cuda")
+    short = torch.zeros((B, D), device="cuda")
+    save = torch.zeros((R, 5 * D), device="cuda")
+    xd, tld, sld = dev(x.reshape(R, D)), dev(tl.reshape(R)), dev(sl)
+    ops.tagru_fwd(dev(xproj), xd, tld, sld, dev(whg), dev(whc), dev(tvec), B, L, hs, short, save)
+
+    wt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref_hs = O.time_aware_gru(wt, xt, torch.tensor(tl, dtype=torch.float64), torch.tensor(sl).long() - 1)
+    ref_short = O.gather_indexes(ref_hs, torch.tensor(sl).long() - 2)
+    assert rel_err(hs.cpu().numpy().reshape(B, L, D), ref_hs.detach().numpy()) < 2e-5
+    assert rel_err(short.cpu().numpy(), ref_short.detach().numpy()) < 2e-5
+
+    d_short = rng.standard_normal((B, D)).astype(np.float32)
+    (ref_short * torch.tensor(d_short, dtype=torch.float64)).sum().backward()
+    d_xproj = torch.full((R, 3 * D), 3.0, device="cuda")
+    rh = torch.full((R, D), 3.0, device="cuda")
+    d_x0 = rng.standard_normal((R, D)).astype(np.float32)
+    d_x = dev(d_x0).clone()
+    d_tv = torch.zeros((B, 8, D), device="cuda")
+    ops.tagru_bwd(dev(d_short), xd, tld, sld, dev(whg), dev(whc), dev(tvec), save, B, L, d_xproj, rh, d_x, d_tv)
+    from mtamrecommender_amd.Model.variables import GRU_SCOPE, GRU_USED
+    # gradients of the parameters the kernel owns directly
+    got_tv = d_tv.cpu().numpy().astype(np.float64).sum(0)
+    for i, n in enumerate(GRU_USED):
+        assert rel_err(got_tv[i], wt[GRU_SCOPE + n].grad.numpy()) < 1e-4, n
+    # the rest goes through the pre-activation gradients: check them via the weight gradients
+    dxp = d_xproj.cpu().numpy().astype(np.float64)
+    sv = save.cpu().numpy().astype(np.float64)
+    hprev = sv[:, 4 * D:5 * D]
+    live = (np.arange(L)[None, :] < (sl[:, None] - 1)).reshape(R)
+    assert np.all(dxp[~live] == 0) and np.all(rh.cpu().numpy()[~live] == 0)
+    x2 = x.reshape(R, D).astype(np.float64)
+    gWg = np.concatenate([x2[live].T @ dxp[live, :2 * D], hprev[live].T @ dxp[live, :2 * D]])
+    gWc = np.concatenate([x2[live].T @ dxp[live, 2 * D:], rh.cpu().numpy().astype(np.float64)[live].T @ dxp[live, 2 * D:]])
+    assert rel_err(gWg, wt[GRU_SCOPE + "gates/kernel"].grad.numpy()) < 1e-4
+    assert rel_err(gWc, wt[GRU_SCOPE + "candidate/kernel"].grad.numpy()) < 1e-4
+    assert rel_err(dxp.sum(0)[:2 * D], wt[GRU_SCOPE + "gates/bias"].grad.numpy()) < 1e-4
+    # d_x: time-gate path in place + x-projection path
+    got_dx = d_x.cpu().numpy().astype(np.float64) - d_x0 + dxp @ Wx.T.astype(np.float64)
+    assert rel_err(got_dx, xt.grad.numpy().reshape(R, D)) < 1e-4
+
+
+# -------------------------------------------------------------- attention
+def _attn_case(rng, B, L, H):
+    scope, inner = "blk/", "vanilla_attention"
+    from mtamrecommender_amd.Model.variables import TIME_GATE
+    w = {}
+    for layer in ("dense", "dense_1", "dense_2"):
+        w[scope + layer + "/kernel"] = rng.uniform(-0.15, 0.15, (D, D))
+        w[scope + layer + "/bias"] = rng.uniform(-0.1, 0.1, D)
+    s = scope + inner + "/"
+    w[s + "_time_input_w"] = rng.uniform(-0.15, 0.15, (D, D))
+    for n in TIME_GATE:
+        w[s + n] = rng.uniform(-0.3, 0.3, (1, L))
+    w[s + "ln/Variable"] = rng.uniform(-0.2, 0.2, D)
+    w[s + "ln/Variable_1"] = rng.uniform(0.8, 1.2, D)
+    w = {k: v.astype(np.float32) for k, v in w.items()}
+    q = rng.uniform(-1, 1, (B, 1, D)).astype(np.float32)
+    x = rng.uniform(-0.5, 0.5, (B, L, D)).astype(np.float32)
+    sl = rng.integers(2, L + 1, size=B).astype(np.int32)
+    sl[0] = 2
+    sl[-1] = L
+    tk = np.cumsum(np.floor(rng.exponential(24.0, (B, L))), axis=1).astype(np.float32) + 250000
+    tq = (tk[np.arange(B), sl - 1] + 0).astype(np.float32)       # mask slot carries the target time
+    return scope, inner, w, q, x, sl, tq, tk
+
+
+@pytest.mark.parametrize("B,L,H", [(4, 6, 1), (9, 50, 2), (128, 50, 1), (8, 200, 8)])
+def test_ta_attn_decode_fwd_bwd(ops, B, L, H):
+    import oracle.mtam_oracle as O
+    from mtamrecommender_amd.Model.variables import TIME_GATE
+    rng = np.random.default_rng(B * 3 + L + H)
+    scope, inner, w, q, x, sl, tq, tk = _attn_case(rng, B, L, H)
+    s = scope + inner + "/"
+    R = B * L
+    wkv = np.concatenate([w[scope + "dense_1/kernel"], w[scope + "dense_2/kernel"]], axis=1)
+    bkv = np.concatenate([w[scope + "dense_1/bias"], w[scope + "dense_2/bias"]])
+    kv = np.maximum(x.reshape(R, D).astype(np.float64) @ wkv + bkv, 0).astype(np.float32)
+    wqt = np.concatenate([w[scope + "dense/kernel"], w[s + "_time_input_w"]], axis=1)
+    tparams = np.concatenate([w[s + n] for n in TIME_GATE], axis=0)           # [5, L]
+    nsave = ops.ta_attn_decode_save_floats(L, H)
+    out = torch.zeros((B, D), device="cuda")
+    save = torch.zeros((B, nsave), device="cuda")
+    args = dict(x=dev(x.reshape(R, D)), kv=dev(kv), tq=dev(tq), tk=dev(tk.reshape(R)), sl=dev(sl),
+                wqt=dev(wqt), tp=dev(tparams), g=dev(w[s + "ln/Variable_1"]))
+    ops.ta_attn_decode_fwd(dev(q.reshape(B, D)), args["x"], args["kv"], 2 * D, 0, D, args["tq"], args["tk"],
+                           args["sl"], args["wqt"], dev(w[scope + "dense/bias"]), args["tp"],
+                           dev(w[s + "ln/Variable"]), args["g"], B, L, H, out, save)
+
+    wt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+    qt = torch.tensor(q, dtype=torch.float64, requires_grad=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref, _ = O.time_aware_multihead_attention(
+        wt, scope, inner, qt, xt, torch.tensor(sl).long(), torch.ones(B).long(),
+        torch.tensor(tq, dtype=torch.float64).unsqueeze(1), torch.tensor(tk, dtype=torch.float64), H)
+    assert rel_err(out.cpu().numpy(), ref.detach().numpy().reshape(B, D)) < 2e-5
+
+    d_out = rng.standard_normal((B, D)).astype(np.float32)
+    (ref.reshape(B, D) * torch.tensor(d_out, dtype=torch.float64)).sum().backward()
+    d_dec = torch.zeros((B, D), device="cuda")
+    d_kv = torch.full((R, 2 * D), 4.0, device="cuda")
+    d_x = torch.full((R, D), 4.0, device="cuda")
+    d_qt = torch.zeros((B, 2 * D), device="cuda")
+    d_tp = torch.zeros((B, 5, L), device="cuda")
+    d_ln = torch.zeros((B, 2, D), device="cuda")
+    ops.ta_attn_decode_bwd(dev(d_out), dev(q.reshape(B, D)), args["x"], args["kv"], 2 * D, 0, D, args["tq"],
+                           args["tk"], args["sl"], args["wqt"], args["tp"], args["g"], save, B, L, H, 0,
+                           d_dec, d_kv, d_x, d_qt, d_tp, d_ln)
+    tol = 2e-4
+    x2 = x.reshape(R, D).astype(np.float64)
+    dkv = d_kv.cpu().numpy().astype(np.float64)
+    dqt = d_qt.cpu().numpy().astype(np.float64)
+    q2 = q.reshape(B, D).astype(np.float64)
+    assert rel_err(x2.T @ dkv[:, :D], wt[scope + "dense_1/kernel"].grad.numpy()) < tol
+    assert rel_err(x2.T @ dkv[:, D:], wt[scope + "dense_2/kernel"].grad.numpy()) < tol
+    assert rel_err(dkv.sum(0)[:D], wt[scope + "dense_1/bias"].grad.numpy()) < tol
+    assert rel_err(q2.T @ dqt[:, :D], wt[scope + "dense/kernel"].grad.numpy()) < tol
+    assert rel_err(q2.T @ dqt[:, D:], wt[s + "_time_input_w"].grad.numpy()) < tol
+    assert rel_err(dqt.sum(0)[:D], wt[scope + "dense/bias"].grad.numpy()) < tol
+    got_tp = d_tp.cpu().numpy().astype(np.float64).sum(0)
+    for i, n in enumerate(TIME_GATE):
+        assert rel_err(got_tp[i], wt[s + n].grad.numpy()[0]) < tol, n
+    got_ln = d_ln.cpu().numpy().astype(np.float64).sum(0)
+    assert rel_err(got_ln[0], wt[s + "ln/Variable"].grad.numpy()) < tol
+    assert rel_err(got_ln[1], wt[s + "ln/Variable_1"].grad.numpy()) < tol
+    assert rel_err(d_dec.cpu().numpy(), qt.grad.numpy().reshape(B, D)) < tol
+    got_dx = d_x.cpu().numpy().astype(np.float64) + dkv @ wkv.T.astype(np.float64)
+    assert rel_err(got_dx, xt.grad.numpy().reshape(R, D)) < tol
+    # padded keys carry exactly zero gradient (the scatter kernel relies on it)
+    pad = (np.arange(L)[None, :] >= sl[:, None]).reshape(R)
+    assert np.all(dkv[pad] == 0) and np.all(d_x.cpu().numpy()[pad] == 0)
+    # accumulate_dx adds on top
+    d_x2 = torch.full((R, D), 1.5, device="cuda")
+    ops.ta_attn_decode_bwd(dev(d_out), dev(q.reshape(B, D)), args["x"], args["kv"], 2 * D, 0, D, args["tq"],
+                           args["tk"], args["sl"], args["wqt"], args["tp"], args["g"], save, B, L, H, 1,
+                           d_dec, d_kv, d_x2, d_qt, d_tp, d_ln)
+    assert np.allclose(d_x2.cpu().numpy(), d_x.cpu().numpy() + 1.5, atol=1e-6)
+
+
+# ------------------------------------------------------------ layer norm
+def test_layer_norm(ops):
+    import oracle.mtam_oracle as O
+    rng = np.random.default_rng(9)
+    rows = 37
+    x = rng.standard_normal((rows, D)).astype(np.float32)
+    beta = rng.standard_normal(D).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, D).astype(np.float32)
+    y = torch.zeros((rows, D), device="cuda")
+    save = torch.zeros((rows, D + 1), device="cuda")
+    ops.layer_norm_fwd(dev(x), dev(beta), dev(gamma), 1e-12, rows, y, save)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+    gt = torch.tensor(gamma, dtype=torch.float64, requires_grad=True)
+    ref = O.layer_norm(xt, bt, gt)
+    assert rel_err(y.cpu().numpy(), ref.detach().numpy()) < 2e-6
+    dy = rng.standard_normal((rows, D)).astype(np.float32)
+    (ref * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    dx = torch.zeros((rows, D), device="cuda")
+    dbg = torch.zeros((2, D), device="cuda")
+    ops.layer_norm_bwd(dev(dy), dev(gamma), save, rows, dx, dbg)
+    assert rel_err(dx.cpu().numpy(), xt.grad.numpy()) < 1e-5
+    assert rel_err(dbg.cpu().numpy()[0], bt.grad.numpy()) < 1e-5
+    assert rel_err(dbg.cpu().numpy()[1], gt.grad.numpy()) < 1e-5
+
+
+# ------------------------------------------------------------ softmax CE
+@pytest.mark.parametrize("B,V", [(3, 10), (128, 3709), (5, 20000)])
+def test_softmax_ce(ops, B, V):
+    rng = np.random.default_rng(V)
+    logits = (rng.standard_normal((B, V)) * 3).astype(np.float32)
+    target = rng.integers(0, V, size=B).astype(np.int32)
+    lse = torch.zeros(B, device="cuda")
+    ce = torch.zeros(B, device="cuda")
+    lg = dev(logits)
+    part = torch.zeros(ops.softmax_ce_partials(B, V), device="cuda")
+    scale = 1.0 / B
+    ops.softmax_ce(lg, V, dev(target), B, V, scale, lse, ce, lg, part)         # gradient in place
+    l64 = logits.astype(np.float64)
+    m = l64.max(1, keepdims=True)
+    ref_lse = (m[:, 0] + np.log(np.exp(l64 - m).sum(1)))
+    assert rel_err(lse.cpu().numpy(), ref_lse) < 1e-6
+    assert rel_err(ce.cpu().numpy(), ref_lse - l64[np.arange(B), target]) < 1e-6
+    g = np.exp(l64 - ref_lse[:, None])
+    g[np.arange(B), target] -= 1
+    assert np.abs(lg.cpu().numpy() - g * scale).max() < 1e-6 * scale * 10
+    l2p = dev(rng.uniform(0, 1, 77).astype(np.float32))
+    loss = torch.zeros(3, device="cuda")
+    ops.loss_reduce(l2p, 77, ce, B, 5e-5, 1.0 / B, loss)
+    l2 = 0.5 * float(l2p.double().sum())
+    ces = float(ce.double().sum())
+    assert np.allclose(loss.cpu().numpy(), [5e-5 * l2 + ces / B, l2, ces / B], rtol=1e-5)
+
+
+# ------------------------------------------------------------------ top-K
+@pytest.mark.parametrize("rows,V,k", [(4, 10, 50), (7, 3709, 50), (3, 70000, 50), (5, 300, 1), (2, 64, 64)])
+def test_topk_bit_exact(ops, rows, V, k):
+    import oracle.mtam_oracle as O
+    rng = np.random.default_rng(rows + V + k)
+    scores = rng.standard_normal((rows, V)).astype(np.float32)
+    scores[0, : min(V, 40)] = 1.25           # a run of exact ties inside the top-k
+    if rows > 1:
+        scores[1] = np.round(scores[1] * 2) / 2          # heavy ties everywhere
+    if rows > 2:
+        scores[2, ::3] = -0.0
+        scores[2, 1::3] = 0.0
+    idx = torch.zeros((rows, k), dtype=torch.int32, device="cuda")
+    val = torch.zeros((rows, k), device="cuda")
+    ops.topk(dev(scores), V, rows, V, k, idx, val)
+    kk = min(k, V)
+    ref = O.top_k(scores, kk)
+    got = idx.cpu().numpy()
+    assert np.array_equal(got[:, :kk], ref)
+    assert np.all(got[:, kk:] == -1)
+    assert np.array_equal(val.cpu().numpy()[:, :kk] + 0.0, np.take_along_axis(scores, ref, 1) + 0.0)
+
+
+# ------------------------------------------------------------ clip + Adam
+def test_clip_and_adam(ops):
+    rng = np.random.default_rng(1)
+    n = 4096 * 3 + 5
+    g = rng.standard_normal(n).astype(np.float32)
+    p0 = rng.standard_normal(n).astype(np.float32)
+    m0 = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    v0 = (rng.uniform(0, 0.1, n)).astype(np.float32)
+    nb = ops.sqnorm_blocks(n)
+    assert nb == 4
+    part = torch.zeros(nb + 2, device="cuda")
+    part[nb] = 2.5
+    part[nb + 1] = 0.5
+    ops.sqnorm_partial(dev(g), n, part)
+    total = float((g.astype(np.float64) ** 2).sum()) + 3.0
+    scale = torch.zeros(2, device="cuda")
+    ops.clip_scale(part, nb + 2, 1.0, scale)
+    norm = np.sqrt(total)
+    assert abs(float(scale[1]) - norm) / norm < 1e-6
+    assert abs(float(scale[0]) - 1.0 * min(1 / norm, 1.0)) < 1e-7
+    ops.clip_scale(part, nb + 2, 1e6, scale)                 # norm below the clip: scale == 1
+    assert float(scale[0]) == 1.0
+    ops.clip_scale(part, nb + 2, 1.0, scale)
+    sc = np.float32(scale[0].item())
+    lr_t, b1, b2, eps = np.float32(1e-3), np.float32(0.9), np.float32(0.999), np.float32(1e-8)
+    hyper = dev(np.array([lr_t, b1, b2, eps], np.float32))
+    for sparse in (0, 1):
+        p, m, v = dev(p0).clone(), dev(m0).clone(), dev(v0).clone()
+        ops.adam(p, m, v, dev(g), n, scale, hyper, sparse)
+        gs = g * sc
+        if sparse:
+            mr = m0 * b1 + gs * (np.float32(1) - b1)
+            vr = v0 * b2 + (gs * gs) * (np.float32(1) - b2)
+        else:
+            mr = m0 + (gs - m0) * (np.float32(1) - b1)
+            vr = v0 + (gs * gs - v0) * (np.float32(1) - b2)
+        pr = p0 - (lr_t * mr) / (np.sqrt(vr) + eps)
+        assert np.allclose(m.cpu().numpy(), mr, rtol=1e-6, atol=1e-9)
+        assert np.allclose(v.cpu().numpy(), vr, rtol=1e-6, atol=1e-9)
+        assert np.allclose(p.cpu().numpy(), pr, rtol=1e-6, atol=1e-7)
