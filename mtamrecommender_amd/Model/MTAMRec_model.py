@@ -1,0 +1,68 @@
+"""MTAM: time-aware GRU -> time-aware attention decoder -> full-catalog softmax.
+Mirror of Model/MTAMRec_model.py:12-38 (MTAMRec_model) and :61-92 (MTAM)."""
+import numpy as np
+
+from .base_model import base_model
+from .time_aware_path import TimeAwarePath
+from .variables import init_variables, mtam_dense_specs
+
+
+class MTAMRec_model(base_model):
+
+    def __init__(self, FLAGS, Embeding, sess):
+        super(MTAMRec_model, self).__init__(FLAGS, Embeding)
+        self.sess = sess
+        self.now_bacth_data_size = "batch_size"          # (sic) placeholder name, reference :17
+        self.num_units = self.FLAGS.num_units
+        self.num_heads = self.FLAGS.num_heads
+        self.num_blocks = self.FLAGS.num_blocks
+        self.dropout_rate = self.FLAGS.dropout           # unused on this path
+        self.regulation_rate = self.FLAGS.regulation_rate
+        self.user_embedding, self.behavior_list_embedding_dense, self.item_list_emb, \
+            self.category_list_emb, self.position_list_emb, self.time_list, self.timelast_list, \
+            self.timenow_list, self.target, self.seq_length = self.embedding.get_embedding(self.num_units)
+        self.max_len = self.FLAGS.length_of_user_history
+        self.build_model()
+        self.init_variables(sess, self.checkpoint_path_dir)
+
+
+class MTAM(MTAMRec_model):
+    """Multi-hop Time-aware Attentive Memory network."""
+
+    def build_model(self, seed=1234):
+        D, L, NB = self.num_units, self.max_len, self.num_blocks
+        if self.embedding.position_count != L:
+            raise ValueError("embedding max_length_seq %d != length_of_user_history %d"
+                             % (self.embedding.position_count, L))
+        specs = mtam_dense_specs(D, L, NB)
+        values = init_variables(specs, seed=seed + 1)
+        live = {s.name: values[s.name] for s in specs if s.trainable_grad}
+        self.dead_variables = {s.name: values[s.name] for s in specs if not s.trainable_grad}
+        device = getattr(self.sess, "device", "cuda:0")
+        self.path = TimeAwarePath(self.embedding.tables(), live, L, self.num_heads, NB,
+                                  self.regulation_rate, self.FLAGS.max_gradient_norm,
+                                  tf_compat_global_norm=self.FLAGS.tf_compat_global_norm, device=device)
+        self.summery()
+
+    # weight injection for parity tests / checkpoint interchange (TF names)
+    def set_variables(self, arrays):
+        import torch
+        p = self.path
+        dense = p.dense_tf()
+        for k, v in arrays.items():
+            if k.startswith("embedding_layer/"):
+                p.tables[k.split("/")[1]].copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)))
+            elif k in dense:
+                dense[k] = np.asarray(v, np.float32)
+            elif k in self.dead_variables:
+                self.dead_variables[k] = np.asarray(v, np.float32)
+            else:
+                raise KeyError(k)
+        p.params.copy_(torch.from_numpy(p.layout.pack(dense)))
+
+    def get_variables(self):
+        out = dict(self.path.dense_tf())
+        for k, v in self.path.tables_numpy().items():
+            out["embedding_layer/" + k] = v
+        out.update(self.dead_variables)
+        return out

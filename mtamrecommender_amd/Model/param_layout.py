@@ -1,0 +1,169 @@
+"""Device layout of the dense (non-table) variables.
+
+The kernels want the reference's variables packed differently from how TF 1.14
+creates them:
+
+* the GRU ``gates/kernel`` [2D,2D] and ``candidate/kernel`` [2D,D]
+  (Model/Modules/time_aware_rnn.py:166-185) are split into their input rows,
+  packed side by side as ``gru/wx`` [D,3D] (one hoisted GEMM), and their
+  recurrent rows ``gru/wh_g`` [D,2D], ``gru/wh_c`` [D,D];
+* the K and V projections of every decoder block
+  (Model/Modules/time_aware_attention.py:251-253) are packed into one
+  ``kv/w`` [D, 2*NB*D] because the keys are the same for every block;
+* per block, ``dense/kernel`` and ``_time_input_w`` (:249,:269-271) form
+  ``blk{i}/wqt`` [D,2D]; the five [1,L] time-gate rows (:295-312) form
+  ``blk{i}/tparams`` [5,L].
+
+All segments live in ONE flat float32 buffer (parameters, gradients, Adam m and
+v share the layout) so that clipping and Adam are single launches.  Segment
+offsets are multiples of 4 floats (16 B).  ``pack``/``unpack`` convert to and
+from TF-named arrays for weight injection and checkpoint interchange.
+"""
+import collections
+
+import numpy as np
+
+from .variables import GRU_DEAD, GRU_SCOPE, GRU_USED, TIME_GATE
+
+Segment = collections.namedtuple("Segment", "name offset shape size")
+
+
+def _align4(n):
+    return (n + 3) // 4 * 4
+
+
+class DenseLayout(object):
+
+    def __init__(self, model, D, L, num_blocks):
+        self.model, self.D, self.L, self.NB = model, D, L, num_blocks
+        segs = [("dense4emb/w", (2 * D, D))]
+        if model == "MTAM":
+            segs += [("gru/wx", (D, 3 * D)), ("gru/bx", (3 * D,)), ("gru/wh_g", (D, 2 * D)),
+                     ("gru/wh_c", (D, D)), ("gru/tvec", (8, D)),
+                     ("kv/w", (D, 2 * num_blocks * D)), ("kv/b", (2 * num_blocks * D,))]
+            for i in range(num_blocks):
+                segs += [("blk%d/wqt" % i, (D, 2 * D)), ("blk%d/bq" % i, (D,)),
+                         ("blk%d/tparams" % i, (5, L)), ("blk%d/ln" % i, (2, D))]
+        else:
+            for i in range(num_blocks):
+                segs += [("blk%d/wqkv" % i, (D, 3 * D)), ("blk%d/bqkv" % i, (3 * D,)),
+                         ("blk%d/wt" % i, (D, D)), ("blk%d/tparams" % i, (5, L, L)),
+                         ("blk%d/ln" % i, (2, D))]
+        segs.append(("head/ln", (2, D)))
+        self.segments = collections.OrderedDict()
+        off = 0
+        for name, shape in segs:
+            size = int(np.prod(shape))
+            self.segments[name] = Segment(name, off, shape, size)
+            off = _align4(off + size)
+        self.total = off
+
+    def view(self, flat, name):
+        s = self.segments[name]
+        return flat[s.offset:s.offset + s.size].view(*s.shape) if hasattr(flat, "view") and not isinstance(flat, np.ndarray) \
+            else flat[s.offset:s.offset + s.size].reshape(s.shape)
+
+    # ------------------------------------------------------------ TF <-> native
+    def _scopes(self):
+        if self.model == "MTAM":
+            return ["NextItemDecoder/decoder/num_blocks_%d/" % i for i in range(self.NB)], "vanilla_attention", \
+                "NextItemDecoder/LayerNorm/"
+        return ["UserHistoryEncoder/encoder/num_blocks_%d/" % i for i in range(self.NB)], "self_attention", \
+            "UserHistoryEncoder/LayerNorm/"
+
+    def pack(self, tf_vars):
+        """TF-named arrays -> flat float32 numpy buffer (pad floats are zero)."""
+        D = self.D
+        flat = np.zeros(self.total, np.float32)
+
+        def put(name, arr):
+            s = self.segments[name]
+            flat[s.offset:s.offset + s.size] = np.asarray(arr, np.float32).reshape(-1)
+
+        put("dense4emb/w", tf_vars["position_embedding/dense4emb/kernel"])
+        scopes, inner, head = self._scopes()
+        if self.model == "MTAM":
+            Wg, Wc = tf_vars[GRU_SCOPE + "gates/kernel"], tf_vars[GRU_SCOPE + "candidate/kernel"]
+            put("gru/wx", np.concatenate([Wg[:D], Wc[:D]], axis=1))
+            put("gru/bx", np.concatenate([tf_vars[GRU_SCOPE + "gates/bias"], tf_vars[GRU_SCOPE + "candidate/bias"]]))
+            put("gru/wh_g", Wg[D:])
+            put("gru/wh_c", Wc[D:])
+            put("gru/tvec", np.stack([tf_vars[GRU_SCOPE + n] for n in GRU_USED]))
+            put("kv/w", np.concatenate([np.concatenate([tf_vars[s + "dense_1/kernel"], tf_vars[s + "dense_2/kernel"]], axis=1)
+                                        for s in scopes], axis=1))
+            put("kv/b", np.concatenate([np.concatenate([tf_vars[s + "dense_1/bias"], tf_vars[s + "dense_2/bias"]])
+                                        for s in scopes]))
+            for i, s in enumerate(scopes):
+                a = s + inner + "/"
+                put("blk%d/wqt" % i, np.concatenate([tf_vars[s + "dense/kernel"], tf_vars[a + "_time_input_w"]], axis=1))
+                put("blk%d/bq" % i, tf_vars[s + "dense/bias"])
+                put("blk%d/tparams" % i, np.concatenate([tf_vars[a + n] for n in TIME_GATE], axis=0))
+                put("blk%d/ln" % i, np.stack([tf_vars[a + "ln/Variable"], tf_vars[a + "ln/Variable_1"]]))
+        else:
+            for i, s in enumerate(scopes):
+                a = s + inner + "/"
+                put("blk%d/wqkv" % i, np.concatenate([tf_vars[s + "dense/kernel"], tf_vars[s + "dense_1/kernel"],
+                                                       tf_vars[s + "dense_2/kernel"]], axis=1))
+                put("blk%d/bqkv" % i, np.concatenate([tf_vars[s + "dense/bias"], tf_vars[s + "dense_1/bias"],
+                                                       tf_vars[s + "dense_2/bias"]]))
+                put("blk%d/wt" % i, tf_vars[a + "_time_input_w"])
+                put("blk%d/tparams" % i, np.stack([tf_vars[a + n] for n in TIME_GATE]))
+                put("blk%d/ln" % i, np.stack([tf_vars[a + "ln/Variable"], tf_vars[a + "ln/Variable_1"]]))
+        put("head/ln", np.stack([tf_vars[head + "beta"], tf_vars[head + "gamma"]]))
+        return flat
+
+    def unpack(self, flat):
+        """flat buffer (numpy) -> TF-named arrays (live variables only)."""
+        D, NB = self.D, self.NB
+        get = lambda name: np.array(self.view(flat, name))
+        out = collections.OrderedDict()
+        out["position_embedding/dense4emb/kernel"] = get("dense4emb/w")
+        scopes, inner, head = self._scopes()
+        if self.model == "MTAM":
+            wx, bx = get("gru/wx"), get("gru/bx")
+            out[GRU_SCOPE + "gates/kernel"] = np.concatenate([wx[:, :2 * D], get("gru/wh_g")], axis=0)
+            out[GRU_SCOPE + "gates/bias"] = bx[:2 * D]
+            out[GRU_SCOPE + "candidate/kernel"] = np.concatenate([wx[:, 2 * D:], get("gru/wh_c")], axis=0)
+            out[GRU_SCOPE + "candidate/bias"] = bx[2 * D:]
+            tv = get("gru/tvec")
+            for j, n in enumerate(GRU_USED):
+                out[GRU_SCOPE + n] = tv[j]
+            kvw, kvb = get("kv/w"), get("kv/b")
+            for i, s in enumerate(scopes):
+                a = s + inner + "/"
+                wqt = get("blk%d/wqt" % i)
+                out[s + "dense/kernel"], out[a + "_time_input_w"] = wqt[:, :D], wqt[:, D:]
+                out[s + "dense/bias"] = get("blk%d/bq" % i)
+                out[s + "dense_1/kernel"] = kvw[:, 2 * i * D:(2 * i + 1) * D]
+                out[s + "dense_2/kernel"] = kvw[:, (2 * i + 1) * D:(2 * i + 2) * D]
+                out[s + "dense_1/bias"] = kvb[2 * i * D:(2 * i + 1) * D]
+                out[s + "dense_2/bias"] = kvb[(2 * i + 1) * D:(2 * i + 2) * D]
+                tp = get("blk%d/tparams" % i)
+                for j, n in enumerate(TIME_GATE):
+                    out[a + n] = tp[j:j + 1]
+                ln = get("blk%d/ln" % i)
+                out[a + "ln/Variable"], out[a + "ln/Variable_1"] = ln[0], ln[1]
+        else:
+            for i, s in enumerate(scopes):
+                a = s + inner + "/"
+                w, bqkv = get("blk%d/wqkv" % i), get("blk%d/bqkv" % i)
+                for j, layer in enumerate(("dense", "dense_1", "dense_2")):
+                    out[s + layer + "/kernel"] = w[:, j * D:(j + 1) * D]
+                    out[s + layer + "/bias"] = bqkv[j * D:(j + 1) * D]
+                out[a + "_time_input_w"] = get("blk%d/wt" % i)
+                tp = get("blk%d/tparams" % i)
+                for j, n in enumerate(TIME_GATE):
+                    out[a + n] = tp[j]
+                ln = get("blk%d/ln" % i)
+                out[a + "ln/Variable"], out[a + "ln/Variable_1"] = ln[0], ln[1]
+        hl = get("head/ln")
+        out[head + "beta"], out[head + "gamma"] = hl[0], hl[1]
+        return out
+
+    def dead_names(self):
+        """Variables the reference creates but never updates (gradient None)."""
+        scopes, inner, _ = self._scopes()
+        names = [s + inner + "/time_output_w3" for s in scopes]
+        if self.model == "MTAM":
+            names += [GRU_SCOPE + n for n in GRU_DEAD]
+        return names

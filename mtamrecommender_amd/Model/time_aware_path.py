@@ -1,0 +1,286 @@
+"""The device-side training/eval step of the time-aware path.
+
+What ``sess.run([loss, merged, train_op], feed)`` (Model/base_model.py:159-164)
+and the eval ``sess.run`` (:201-202) execute in the reference becomes, here, a
+fixed sequence of ``mtam_*`` launches over pre-allocated HBM buffers:
+
+  forward   gather -> dense4emb GEMM -> x-projection GEMM -> time-aware GRU
+            -> K/V GEMM -> NB decoder blocks -> head LN -> logits GEMM
+            -> softmax CE                                   
+  backward  the same chain reversed, weight gradients by split-K GEMMs,
+            embedding rows by atomic scatter-add                     (K11)
+  update    global-norm clip -> Adam on the flat dense buffer and on the four
+            tables                                                (K12, K13)
+
+Nothing is allocated inside a step, so a step can be captured into a hipGraph
+(``torch.cuda.CUDAGraph``) and replayed; dynamic inputs live in fixed device
+buffers that ``load_feed`` overwrites.  Data-parallel training calls
+``allreduce_fn`` between backward and update (see ``data_parallel.py``).
+"""
+import numpy as np
+import torch
+
+from .. import hip_ops as ops
+from .param_layout import DenseLayout
+
+D = 128
+INT_FIELDS = ("user_id", "item_list", "category_list", "position_list", "target_item_id", "seq_length")
+FLOAT_FIELDS = ("time_list", "timelast_list", "target_item_time")
+
+
+class _Batch(object):
+    """Per-batch-size device buffers (activations, gradients, saved state)."""
+
+    def __init__(self, path, B):
+        dev, L, NB, H = path.device, path.L, path.NB, path.H
+        R = B * L
+        V = path.item_rows
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        i = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)
+        self.B, self.R = B, R
+        # feed (fixed addresses; load_feed copies into them)
+        self.feed = {"user_id": i(B), "item_list": i(B, L), "category_list": i(B, L), "position_list": i(B, L),
+                     "target_item_id": i(B), "seq_length": i(B),
+                     "time_list": f(B, L).zero_(), "timelast_list": f(B, L).zero_(), "target_item_time": f(B).zero_()}
+        self.host = {k: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k, v in self.feed.items()}
+        # forward activations
+        self.ic, self.pos, self.user = f(R, 2 * D), f(R, D), f(B, D)
+        self.zr, self.x = f(R, D), f(R, D)
+        self.xproj, self.hs, self.short = f(R, 3 * D), f(R, D), f(B, D)
+        self.gru_save = f(R, 5 * D)
+        self.kv = f(R, 2 * NB * D)
+        self.dec = [self.short] + [f(B, D) for _ in range(NB)]
+        self.attn_save = [f(B, ops.ta_attn_decode_save_floats(L, H)) for _ in range(NB)]
+        self.pred, self.ln_save = f(B, D), f(B, D + 1)
+        self.logits = f(B, V)
+        self.lse, self.ce = f(B), f(B)
+        self.ce_partial = f(ops.softmax_ce_partials(B, V))
+        self.l2_partial = f(ops.emb_gather_partials(B, L))
+        self.loss = f(3)
+        # backward
+        self.d_dec = [f(B, D) for _ in range(NB + 1)]
+        self.d_kv = f(R, 2 * NB * D)
+        self.d_x, self.d_z = f(R, D), f(R, D)
+        self.d_qt = f(B, 2 * D)
+        self.d_tp_partial, self.d_ln_partial = f(B, 5 * L), f(B, 2 * D)
+        self.d_xproj, self.rh = f(R, 3 * D), f(R, D)
+        self.d_tvec_partial = f(B, 8 * D)
+        self.d_ic = f(R, 2 * D)
+        self.d_pred = f(B, D)
+        self.n_slot = ops.emb_scatter_partials(B, L)
+        self.topk_idx = torch.zeros((B, 50), dtype=torch.int32, device=dev)
+
+
+class TimeAwarePath(object):
+    """Owns parameters, optimizer state and the kernel sequence for MTAM."""
+
+    def __init__(self, tables, dense_tf, L, num_heads, num_blocks, regulation_rate, max_gradient_norm,
+                 tf_compat_global_norm=True, device="cuda:0"):
+        self.device = torch.device(device)
+        self.L, self.H, self.NB = L, num_heads, num_blocks
+        self.reg, self.clip = float(regulation_rate), float(max_gradient_norm)
+        self.tf_compat = bool(tf_compat_global_norm)
+        self.layout = DenseLayout("MTAM", D, L, num_blocks)
+        dev = self.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        # tables: "user", "item", "category", "position"
+        self.tables = {k: t(v) for k, v in tables.items()}
+        for k, v in self.tables.items():
+            if v.shape[1] != D:
+                raise ValueError("this build supports num_units == %d only (table %s has %d)" % (D, k, v.shape[1]))
+        self.item_rows = self.tables["item"].shape[0]
+        self.params = t(self.layout.pack(dense_tf))
+        P = self.layout.total
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m, self.v = z(P), z(P)
+        self.tm = {k: torch.zeros_like(v) for k, v in self.tables.items()}
+        self.tv = {k: torch.zeros_like(v) for k, v in self.tables.items()}
+        # one zeroed-per-step arena: dense gradients + the three small table gradients
+        sizes = [P] + [self.tables[k].numel() for k in ("category", "position", "user")]
+        self.zero_arena = z(sum(sizes))
+        o = 0
+        self.grads = self.zero_arena[o:o + P]; o += P
+        self.g_tab = {}
+        for k in ("category", "position", "user"):
+            n = self.tables[k].numel()
+            self.g_tab[k] = self.zero_arena[o:o + n].view_as(self.tables[k]); o += n
+        self.g_tab["item"] = torch.empty_like(self.tables["item"])
+        # global-norm partial sums: [dense | item dense | slots or small tables]
+        self.nb_dense = ops.sqnorm_blocks(P)
+        self.nb_item = ops.sqnorm_blocks(self.tables["item"].numel())
+        self.nb_small = [ops.sqnorm_blocks(self.tables[k].numel()) for k in ("category", "position", "user")]
+        self.scale = z(2)
+        self.hyper = z(4)
+        self.hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        self.beta1_power, self.beta2_power = np.float32(0.9), np.float32(0.999)
+        self._batches = {}
+        self._norm_partials = {}
+        self.allreduce_fn = None        # set by data_parallel.attach()
+        self.global_batch = None        # mean divisor across ranks (None: local batch)
+
+    # ----------------------------------------------------------------- helpers
+    def seg(self, name, flat=None):
+        return self.layout.view(self.params if flat is None else flat, name)
+
+    def batch(self, B):
+        if B not in self._batches:
+            self._batches[B] = _Batch(self, B)
+            n = self.nb_dense + self.nb_item + max(self._batches[B].n_slot, sum(self.nb_small))
+            self._norm_partials[B] = torch.zeros(n, dtype=torch.float32, device=self.device)
+        return self._batches[B]
+
+    def load_feed(self, feed):
+        """Host feed arrays (Embedding.make_feed_dic_new) -> the fixed device buffers."""
+        B = len(feed["user_id"])
+        bt = self.batch(B)
+        for k in INT_FIELDS + FLOAT_FIELDS:
+            h = bt.host[k]
+            h.copy_(torch.from_numpy(np.ascontiguousarray(feed[k])).to(h.dtype).view(h.shape))
+            bt.feed[k].copy_(h, non_blocking=True)
+        return bt
+
+    def set_learning_rate(self, lr):
+        """lr placeholder (float64, Model/base_model.py:25) -> Adam's lr_t [TF1.14]."""
+        lr32 = np.float32(lr)
+        lr_t = lr32 * np.sqrt(np.float32(1) - self.beta2_power) / (np.float32(1) - self.beta1_power)
+        self.hyper_host[0] = float(lr_t)
+        self.hyper_host[1], self.hyper_host[2], self.hyper_host[3] = 0.9, 0.999, 1e-8
+        self.hyper.copy_(self.hyper_host, non_blocking=True)
+
+    def advance_beta_powers(self):
+        self.beta1_power = np.float32(self.beta1_power * np.float32(0.9))
+        self.beta2_power = np.float32(self.beta2_power * np.float32(0.999))
+
+    # ----------------------------------------------------------------- forward
+    def forward(self, bt, training=True):
+        B, R, L, NB, H = bt.B, bt.R, self.L, self.NB, self.H
+        fd, T = bt.feed, self.tables
+        ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
+                           fd["category_list"], fd["position_list"], fd["user_id"], B, L, 1,
+                           bt.ic, bt.pos, bt.user, bt.l2_partial)
+        ops.gemm(bt.ic, self.seg("dense4emb/w"), bt.x, epilogue=ops.EPI_RELU_ADD, aux_in=bt.pos, aux_out=bt.zr)
+        ops.gemm(bt.x, self.seg("gru/wx"), bt.xproj, epilogue=ops.EPI_BIAS, bias=self.seg("gru/bx"))
+        ops.tagru_fwd(bt.xproj, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
+                      self.seg("gru/wh_c"), self.seg("gru/tvec"), B, L, bt.hs, bt.short,
+                      bt.gru_save if training else None)
+        ops.gemm(bt.x, self.seg("kv/w"), bt.kv, epilogue=ops.EPI_BIAS_RELU, bias=self.seg("kv/b"))
+        for i in range(NB):
+            ln = self.seg("blk%d/ln" % i)
+            ops.ta_attn_decode_fwd(bt.dec[i], bt.x, bt.kv, 2 * NB * D, 2 * i * D, (2 * i + 1) * D,
+                                   fd["target_item_time"], fd["time_list"], fd["seq_length"],
+                                   self.seg("blk%d/wqt" % i), self.seg("blk%d/bq" % i),
+                                   self.seg("blk%d/tparams" % i), ln[0], ln[1], B, L, H, bt.dec[i + 1],
+                                   bt.attn_save[i] if training else None)
+        hl = self.seg("head/ln")
+        ops.layer_norm_fwd(bt.dec[NB], hl[0], hl[1], 1e-12, B, bt.pred, bt.ln_save if training else None)
+        ops.gemm(bt.pred, T["item"], bt.logits, trans_b=True)
+
+    def loss_and_logit_grad(self, bt):
+        B, V = bt.B, self.item_rows
+        gb = B if self.global_batch is None else self.global_batch
+        # logits -> lse, ce; then d_logits in place
+        ops.softmax_ce(bt.logits, V, bt.feed["target_item_id"], B, V, 1.0 / gb, bt.lse, bt.ce, bt.logits,
+                       bt.ce_partial)
+        ops.loss_reduce(bt.l2_partial, bt.l2_partial.numel(), bt.ce, B, self.reg, 1.0 / gb, bt.loss)
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, bt):
+        B, R, L, NB, H = bt.B, bt.R, self.L, self.NB, self.H
+        fd, T, G = bt.feed, self.tables, self.grads
+        gseg = lambda name: self.layout.view(G, name)
+        part = self._norm_partials[B]
+        self.zero_arena.zero_()
+        # scoring: dE = G^T pred (dense, every row), d_pred = G E
+        ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
+        if self.tf_compat:
+            ops.sqnorm_partial(self.g_tab["item"], self.g_tab["item"].numel(), part[self.nb_dense:])
+        bt.d_pred.zero_()
+        split_v = max(1, min(64, self.item_rows // 512))
+        ops.gemm(bt.logits, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v)
+        ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_dec[NB], gseg("head/ln"))
+        split_r = max(1, min(32, R // 256))
+        for i in reversed(range(NB)):
+            ln = self.seg("blk%d/ln" % i)
+            ops.ta_attn_decode_bwd(bt.d_dec[i + 1], bt.dec[i], bt.x, bt.kv, 2 * NB * D, 2 * i * D,
+                                   (2 * i + 1) * D, fd["target_item_time"], fd["time_list"],
+                                   fd["seq_length"], self.seg("blk%d/wqt" % i), self.seg("blk%d/tparams" % i),
+                                   ln[1], bt.attn_save[i], B, L, H, 0 if i == NB - 1 else 1,
+                                   bt.d_dec[i], bt.d_kv, bt.d_x, bt.d_qt, bt.d_tp_partial, bt.d_ln_partial)
+            ops.gemm(bt.dec[i], bt.d_qt, gseg("blk%d/wqt" % i), trans_a=True)
+            ops.colsum_atomic(bt.d_qt, gseg("blk%d/bq" % i), rows=B, cols=D, ld=2 * D)
+            ops.colsum_atomic(bt.d_tp_partial, gseg("blk%d/tparams" % i).view(-1))
+            ops.colsum_atomic(bt.d_ln_partial, gseg("blk%d/ln" % i).view(-1))
+        # keys/values: d_x += d_kv . Wkv^T ; dWkv, dbkv
+        ops.gemm(bt.d_kv, self.seg("kv/w"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM)
+        ops.gemm(bt.x, bt.d_kv, gseg("kv/w"), trans_a=True, epilogue=ops.EPI_ATOMIC, split_k=split_r)
+        ops.colsum_atomic(bt.d_kv, gseg("kv/b"))
+        # GRU
+        ops.tagru_bwd(bt.d_dec[0], bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
+                      self.seg("gru/wh_c"), self.seg("gru/tvec"), bt.gru_save, B, L, bt.d_xproj, bt.rh,
+                      bt.d_x, bt.d_tvec_partial)
+        ops.colsum_atomic(bt.d_tvec_partial, gseg("gru/tvec").view(-1))
+        ops.gemm(bt.d_xproj, self.seg("gru/wx"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM_MASK,
+                 aux_in=bt.zr, aux_out=bt.d_z)
+        ops.gemm(bt.x, bt.d_xproj, gseg("gru/wx"), trans_a=True, epilogue=ops.EPI_ATOMIC, split_k=split_r)
+        ops.colsum_atomic(bt.d_xproj, gseg("gru/bx"))
+        hprev = bt.gru_save.view(-1)[4 * D:]
+        ops.gemm(hprev, bt.d_xproj, gseg("gru/wh_g"), trans_a=True, epilogue=ops.EPI_ATOMIC, split_k=split_r,
+                 M=D, N=2 * D, K=R, lda=5 * D, ldb=3 * D, ldc=2 * D)
+        ops.gemm(bt.rh, bt.d_xproj.view(-1)[2 * D:], gseg("gru/wh_c"), trans_a=True, epilogue=ops.EPI_ATOMIC,
+                 split_k=split_r, M=D, N=D, K=R, lda=D, ldb=3 * D, ldc=D)
+        # dense4emb
+        ops.gemm(bt.d_z, self.seg("dense4emb/w"), bt.d_ic, trans_b=True)
+        ops.gemm(bt.ic, bt.d_z, gseg("dense4emb/w"), trans_a=True, epilogue=ops.EPI_ATOMIC, split_k=split_r)
+        # tables
+        slot_part = part[self.nb_dense + self.nb_item:]
+        ops.emb_scatter_add_bwd(bt.d_ic, bt.d_x, bt.ic, bt.pos, bt.user, fd["item_list"], fd["category_list"],
+                                fd["position_list"], fd["user_id"], fd["seq_length"], B, L, self.reg, 1,
+                                self.g_tab["item"], self.g_tab["category"], self.g_tab["position"],
+                                self.g_tab["user"], slot_part)
+
+    # ------------------------------------------------------------------ update
+    def clip_and_apply(self, bt):
+        B = bt.B
+        part = self._norm_partials[B]
+        ops.sqnorm_partial(self.grads, self.grads.numel(), part)
+        if self.tf_compat:
+            n = self.nb_dense + self.nb_item + bt.n_slot
+        else:
+            o = self.nb_dense
+            ops.sqnorm_partial(self.g_tab["item"], self.g_tab["item"].numel(), part[o:])
+            o += self.nb_item
+            for k, nb in zip(("category", "position", "user"), self.nb_small):
+                ops.sqnorm_partial(self.g_tab[k], self.g_tab[k].numel(), part[o:])
+                o += nb
+            n = o
+        ops.clip_scale(part, n, self.clip, self.scale)
+        ops.adam(self.params, self.m, self.v, self.grads, self.grads.numel(), self.scale, self.hyper, 0)
+        for k in ("item", "category", "position", "user"):
+            ops.adam(self.tables[k], self.tm[k], self.tv[k], self.g_tab[k], self.tables[k].numel(),
+                     self.scale, self.hyper, 1)
+
+    def train_kernels(self, bt):
+        """Everything between feed upload and loss read-back; capturable."""
+        self.forward(bt, training=True)
+        self.loss_and_logit_grad(bt)
+        self.backward(bt)
+        if self.allreduce_fn is not None:
+            self.allreduce_fn(self, bt)
+        self.clip_and_apply(bt)
+
+    def eval_kernels(self, bt, k=50):
+        self.forward(bt, training=False)
+        ops.topk(bt.logits, self.item_rows, bt.B, self.item_rows, k, bt.topk_idx)
+
+    # ------------------------------------------------------- weights in / out
+    def dense_tf(self):
+        return self.layout.unpack(self.params.detach().cpu().numpy())
+
+    def grads_tf(self):
+        out = self.layout.unpack(self.grads.detach().cpu().numpy())
+        for k in ("user", "item", "category", "position"):
+            out["embedding_layer/" + k] = self.g_tab[k].detach().cpu().numpy()
+        return out
+
+    def tables_numpy(self):
+        return {k: v.detach().cpu().numpy() for k, v in self.tables.items()}

@@ -92,9 +92,27 @@ struct ScatterArgs {
   int work_blocks;
 };
 
-// Row job j: [0,R) item, [R,2R) category, [2R,3R) position, [3R,3R+B) user.
-// One half wave per job; lane li adds floats li, li+32, li+64, li+96 of the row,
-// so each atomic wave instruction covers two 128-B segments in two rows.
+// Wave slot s -> two consecutive rows of ONE table (wave-uniform choice):
+//   [0, P) item, [P, 2P) category, [2P, 3P) position with P = ceil(R/2); then ceil(B/2) user slots.
+// One half wave per row; lane li adds floats li, li+32, li+64, li+96 of the row, so every
+// atomic wave instruction covers two 128-B segments in two rows.
+__device__ __forceinline__ float scatter_row(const float *__restrict__ d, const float *__restrict__ e,
+                                             float *__restrict__ g, float reg, int li) {
+  float v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = li + 32 * q;
+    v[q] = reg * e[c] + (d ? d[c] : 0.f);
+  }
+  float sq = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    atomicAdd(g + li + 32 * q, v[q]);
+    sq += v[q] * v[q];
+  }
+  return sq;
+}
+
 __global__ __launch_bounds__(256) void emb_scatter_kernel(ScatterArgs p) {
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, li = lane & 31;
@@ -120,12 +138,15 @@ __global__ __launch_bounds__(256) void emb_scatter_kernel(ScatterArgs p) {
     if (n_pad > 0) {
       const float w = p.reg * (float)n_pad;
       const int r = first;
+      float *gi = p.g_item + (size_t)clamp_id(p.item_ids[r], p.item_rows) * D;
+      float *gc = p.g_cat + (size_t)clamp_id(p.cat_ids[r], p.cat_rows) * D;
+      float *gp = p.g_pos + (size_t)clamp_id(p.pos_ids[r], p.pos_rows) * D;
       for (int e = lane; e < D; e += 64) {
         const float vi = p.ic[(size_t)r * 2 * D + e], vc = p.ic[(size_t)r * 2 * D + D + e];
         const float vp = p.pos[(size_t)r * D + e];
-        atomicAdd(p.g_item + (size_t)clamp_id(p.item_ids[r], p.item_rows) * D + e, w * vi);
-        atomicAdd(p.g_cat + (size_t)clamp_id(p.cat_ids[r], p.cat_rows) * D + e, w * vc);
-        atomicAdd(p.g_pos + (size_t)clamp_id(p.pos_ids[r], p.pos_rows) * D + e, w * vp);
+        atomicAdd(gi + e, w * vi);
+        atomicAdd(gc + e, w * vc);
+        atomicAdd(gp + e, w * vp);
         const float a = p.reg * vi, b = p.reg * vc, c = p.reg * vp;
         sq += (float)n_pad * (a * a + b * b + c * c);
       }
@@ -136,48 +157,37 @@ __global__ __launch_bounds__(256) void emb_scatter_kernel(ScatterArgs p) {
   }
 
   const int wave_id = blockIdx.x * 4 + wave_in_block;
-  const int total = 3 * R + (p.with_user ? p.B : 0);
+  const int P = (R + 1) / 2;
+  const int total = 3 * P + (p.with_user ? (p.B + 1) / 2 : 0);
   float sq = 0.f;
-#pragma unroll
   for (int i = 0; i < SLOTS_PER_WAVE; ++i) {
-    const int j = (wave_id * SLOTS_PER_WAVE + i) * 2 + half;
-    if (j >= total) continue;
-    const float *d = nullptr, *e;
-    float *g;
-    bool live = true;
-    if (j < 3 * R) {
-      const int t = j / R, r = j - t * R;
-      const int b = r / p.L;
-      live = (r - b * p.L) < min(max(p.seq_len[b], 0), p.L);
-      if (t == 0) {
-        d = p.d_ic + (size_t)r * 2 * D;
-        e = p.ic + (size_t)r * 2 * D;
-        g = p.g_item + (size_t)clamp_id(p.item_ids[r], p.item_rows) * D;
-      } else if (t == 1) {
-        d = p.d_ic + (size_t)r * 2 * D + D;
-        e = p.ic + (size_t)r * 2 * D + D;
-        g = p.g_cat + (size_t)clamp_id(p.cat_ids[r], p.cat_rows) * D;
-      } else {
-        d = p.d_pos + (size_t)r * D;
-        e = p.pos + (size_t)r * D;
-        g = p.g_pos + (size_t)clamp_id(p.pos_ids[r], p.pos_rows) * D;
+    const int s = wave_id * SLOTS_PER_WAVE + i;          // wave-uniform
+    if (s >= total) break;
+    if (s < 3 * P) {
+      const int t = s / P;                                 // wave-uniform table
+      const int r = 2 * (s - t * P) + half;
+      bool live = r < R;
+      if (live) {
+        const int b = r / p.L;
+        live = (r - b * p.L) < min(max(p.seq_len[b], 0), p.L);
+      }
+      if (live) {
+        if (t == 0) {
+          sq += scatter_row(p.d_ic + (size_t)r * 2 * D, p.ic + (size_t)r * 2 * D,
+                            p.g_item + (size_t)clamp_id(p.item_ids[r], p.item_rows) * D, p.reg, li);
+        } else if (t == 1) {
+          sq += scatter_row(p.d_ic + (size_t)r * 2 * D + D, p.ic + (size_t)r * 2 * D + D,
+                            p.g_cat + (size_t)clamp_id(p.cat_ids[r], p.cat_rows) * D, p.reg, li);
+        } else {
+          sq += scatter_row(p.d_pos + (size_t)r * D, p.pos + (size_t)r * D,
+                            p.g_pos + (size_t)clamp_id(p.pos_ids[r], p.pos_rows) * D, p.reg, li);
+        }
       }
     } else {
-      const int b = j - 3 * R;
-      e = p.user + (size_t)b * D;
-      g = p.g_user + (size_t)clamp_id(p.user_ids[b], p.user_rows) * D;
-    }
-    if (!live) continue;
-    float v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = li + 32 * q;
-      v[q] = p.reg * e[c] + (d ? d[c] : 0.f);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      atomicAdd(g + li + 32 * q, v[q]);
-      sq += v[q] * v[q];
+      const int b = 2 * (s - 3 * P) + half;
+      if (b < p.B)
+        sq += scatter_row(nullptr, p.user + (size_t)b * D,
+                          p.g_user + (size_t)clamp_id(p.user_ids[b], p.user_rows) * D, p.reg, li);
     }
   }
   sq = wave_sum(sq);
@@ -190,8 +200,8 @@ int gather_waves(int B, int L) {
   return (total + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE;
 }
 int scatter_work_blocks(int B, int L) {
-  const int jobs = 3 * B * L + B;
-  const int waves = (jobs + 2 * SLOTS_PER_WAVE - 1) / (2 * SLOTS_PER_WAVE);
+  const int slots = 3 * ((B * L + 1) / 2) + (B + 1) / 2;
+  const int waves = (slots + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE;
   return (waves + 3) / 4;
 }
 
