@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""Headline benchmark: MTAM training step, ml-1m shapes, synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step (embedding gather -> time-aware GRU ->
+time-aware attention -> full-catalog softmax -> backward -> global-norm clip ->
+Adam on every variable) on a batch of 128 synthetic ml-1m-shaped sequences per
+GPU (seq_len 50, emb 128, fp32).  Inputs are resident in HBM before the timed
+region; the region is bracketed by barrier + synchronize, the slowest rank's
+time counts, and rank 0 prints one JSON line.  value = sequences/s over all
+ranks.  Extra objects on the same line:
+  roofline      embedding gather kernel: algorithmic bytes / HIP-event time vs HBM peak
+  cpu_baseline  the CPU restatement of the TF1.14 graph (oracle) timed on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3
+L, D, NB, H, B_PER_GPU = 50, 128, 1, 1, 128
+
+
+def gather_bytes_per_seq(L, D, e=4):
+    return (3 * L + 1) * (2 * D * e + 4)          # read row + write row + index
+
+
+def scatter_bytes_per_seq(L, D):
+    return (3 * L + 1) * (3 * D * 4 + 4)          # read grad row + RMW table-grad row + index
+
+
+def time_kernel(fn, iters, torch):
+    """Average duration of back-to-back launches, HIP events on the launch stream."""
+    for _ in range(5):
+        fn()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(iters):
+        fn()
+    stop.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(stop) * 1e-3 / iters
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(records_batches, FLAGS, arrays, budget_s=15.0):
+    """Oracle (torch-CPU fp32, unfused, autograd) on the host cores: sequences/s."""
+    import torch
+    import oracle.mtam_oracle as O
+    from mtamrecommender_amd.Embedding.feed import pad_batch
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log("cpu baseline on %d threads (os.cpu_count() = %s)" % (cores, os.cpu_count()))
+    arrays = {k: v.copy() for k, v in arrays.items()}
+    state = O.AdamState(arrays)
+    feeds = [pad_batch(b, L) for b in records_batches]
+    times = []
+    t_begin = time.perf_counter()
+    i = 0
+    while True:
+        t0 = time.perf_counter()
+        O.train_step("MTAM", arrays, state, feeds[i % len(feeds)], 1e-3, H, NB, FLAGS.regulation_rate,
+                     FLAGS.max_gradient_norm, True)
+        times.append(time.perf_counter() - t0)
+        i += 1
+        if i >= 3 + 30 or (time.perf_counter() - t_begin > budget_s and i >= 3 + 3):
+            break
+    timed = times[3:]
+    med = float(np.median(timed))
+    return {"value": B_PER_GPU / med, "unit": "sequences/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d training steps of batch %d after 3 warm-up steps (median step %.1f ms); "
+                      "CPU restatement of the TF1.14 graph (oracle/mtam_oracle.py, torch-CPU fp32)"
+                      % (len(timed), B_PER_GPU, med * 1e3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--id-dist", default="zipf", choices=["zipf", "uniform"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (see the module docstring)")
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from mtamrecommender_amd import data_parallel, hip_ops as ops
+    from mtamrecommender_amd.config.model_parameter import model_parameter
+    from mtamrecommender_amd.data.synthetic import ML1M, SyntheticCatalog, make_records
+    from mtamrecommender_amd.Embedding.Behavior_embedding_time_aware_attention import \
+        Behavior_embedding_time_aware_attention
+    from mtamrecommender_amd.Model.base_model import Session
+    from mtamrecommender_amd.Model.MTAMRec_model import MTAM
+
+    FLAGS = model_parameter().get_parameter("MTAMb1_movielen").FLAGS
+    FLAGS.num_blocks, FLAGS.num_heads, FLAGS.length_of_user_history = NB, H, L
+    FLAGS.checkpoint_path_dir = "/tmp/mtam_bench_ckpt"
+    cat = SyntheticCatalog(seed=1234, **ML1M)
+    emb = Behavior_embedding_time_aware_attention(True, cat.user_count, cat.item_count, cat.category_count, L,
+                                                  seed=1234)
+    model = MTAM(FLAGS, emb, Session(device))
+    p = model.path
+    if world > 1:
+        data_parallel.attach(p, world)
+        data_parallel.broadcast_parameters(p)
+    arrays0 = model.get_variables() if rank == 0 else None
+
+    # synthetic records: 32 distinct batches per rank, staged in HBM before the timed region
+    n_batches = 32
+    records = make_records(cat, n_batches * B_PER_GPU, L, seed=1234 + 977 * rank, id_dist=args.id_dist)
+    batches = [records[i * B_PER_GPU:(i + 1) * B_PER_GPU] for i in range(n_batches)]
+    feeds = [emb.make_feed_dic_new(b) for b in batches]
+    for f in feeds:
+        emb.validate_ids(f)
+    lr = 1e-3
+    staged = [p.stage(f, lr) for f in feeds]
+    total = args.warmup + args.steps
+    # Adam's lr_t per step (beta powers advance in float32 like TF's accumulators)
+    hyper = np.zeros((total + 1, 4), np.float32)
+    b1p, b2p = np.float32(0.9), np.float32(0.999)
+    for i in range(total + 1):
+        hyper[i] = [np.float32(lr) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p), 0.9, 0.999, 1e-8]
+        b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+    hyper_dev = torch.from_numpy(hyper).to(device)
+    bt = p.batch(B_PER_GPU)
+    loss_hist = torch.zeros(total + 1, device=device)
+
+    def step(i):
+        bt.arena.copy_(staged[i % n_batches], non_blocking=True)      # device -> device, 128 KB
+        bt.hyper.copy_(hyper_dev[i], non_blocking=True)
+        model.step_train(bt)
+        loss_hist[i].copy_(bt.loss[0], non_blocking=True)
+
+    log("rank %d: model built, %d batches staged" % (rank, n_batches))
+    for i in range(args.warmup):
+        step(i)
+    log("rank %d: warm-up done" % rank)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = data_parallel.max_over_ranks(elapsed, device)
+
+    log("rank %d: timed region %.3f s for %d steps" % (rank, elapsed, args.steps))
+    losses = loss_hist.cpu().numpy()
+    if not np.all(np.isfinite(losses[:total])):
+        raise SystemExit("non-finite training loss")
+
+    # ---- per-kernel roofline legs (rank 0): back-to-back launches between HIP events
+    result = None
+    if rank == 0:
+        fd, T = bt.feed, p.tables
+        t_gather = time_kernel(lambda: ops.emb_gather_fwd(
+            T["item"], T["category"], T["position"], T["user"], fd["item_list"], fd["category_list"],
+            fd["position_list"], fd["user_id"], B_PER_GPU, L, 1, bt.ic, bt.pos, bt.user, bt.l2_partial), 300, torch)
+        part = torch.zeros(ops.emb_scatter_partials(B_PER_GPU, L), device=device)
+        t_scatter = time_kernel(lambda: ops.emb_scatter_add_bwd(
+            bt.d_ic, bt.d_x, bt.ic, bt.pos, bt.user, fd["item_list"], fd["category_list"], fd["position_list"],
+            fd["user_id"], fd["seq_length"], B_PER_GPU, L, p.reg, 1, p.g_tab["item"], p.g_tab["category"],
+            p.g_tab["position"], p.g_tab["user"], part), 300, torch)
+        gb = gather_bytes_per_seq(L, D) * B_PER_GPU
+        sb = scatter_bytes_per_seq(L, D) * B_PER_GPU
+        log("gather %.2f us, scatter-add %.2f us per launch" % (t_gather * 1e6, t_scatter * 1e6))
+        recall = model.recall_at(model.sess, batches[0], 20)
+        result = {
+            "metric": "training sequences/sec", "value": B_PER_GPU * world * args.steps / elapsed,
+            "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MTAMRec training step, ml-1m-shaped synthetic (3706 items, 301 categories, "
+                                   "4832 users), seq_len=50 emb=128 num_blocks=1 num_heads=1, batch=128 per GPU",
+                       "global_batch": B_PER_GPU * world, "seq_len": L, "parallelism": "dp%d" % world,
+                       "id_dist": args.id_dist, "optimizer": "adam", "hipgraph": bool(model.use_graph)},
+            "recall_at_20": recall, "loss_first": float(losses[0]), "loss_last": float(losses[total - 1]),
+            "roofline": {"kernel": "emb_gather_kernel", "bound": "hbm", "achieved": gb / t_gather / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / t_gather / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "bytes_per_launch": gb, "us_per_launch": t_gather * 1e6},
+            "roofline_scatter_add": {"kernel": "emb_scatter_kernel", "bound": "hbm", "achieved": sb / t_scatter / 1e9,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": sb / t_scatter / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                     "bytes_per_launch": sb, "us_per_launch": t_scatter * 1e6},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(batches[:8], FLAGS, arrays0)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

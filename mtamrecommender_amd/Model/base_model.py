@@ -167,15 +167,25 @@ class base_model(object):
             self._graphs[key] = g
         g.replay()
 
+    def step_train(self, bt):
+        """One training step on the feed already in ``bt.arena``.  With data parallelism
+        the RCCL exchange runs between two captured graphs."""
+        p = self.path
+        if p.allreduce_fn is None:
+            self._run("train", bt, p.train_kernels)
+        else:
+            self._run("train_fb", bt, p.forward_backward_kernels)
+            p.allreduce_fn(p, bt)
+            self._run("train_up", bt, p.clip_and_apply)
+        p.advance_beta_powers()
+
     def train(self, sess, batch_data, learning_rate, add_summary=False, global_step=0, epoch=0):
         """One optimizer step on one batch -> (loss, summary) (reference :150-167)."""
         input_dic = self.embedding.make_feed_dic_new(batch_data=batch_data)
         self.embedding.validate_ids(input_dic)
         p = self.path
-        bt = p.load_feed(input_dic)
-        p.set_learning_rate(learning_rate)
-        self._run("train", bt, p.train_kernels)
-        p.advance_beta_powers()
+        bt = p.load_feed(input_dic, learning_rate)
+        self.step_train(bt)
         loss = bt.loss.cpu().numpy()
         summary = {"normalized Training Loss": float(loss[0]), "l2_norm": float(loss[1]),
                    "Training Loss": float(loss[2]), "Learning_rate": float(learning_rate)}

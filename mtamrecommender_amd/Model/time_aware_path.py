@@ -38,11 +38,24 @@ class _Batch(object):
         f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         i = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)
         self.B, self.R = B, R
-        # feed (fixed addresses; load_feed copies into them)
-        self.feed = {"user_id": i(B), "item_list": i(B, L), "category_list": i(B, L), "position_list": i(B, L),
-                     "target_item_id": i(B), "seq_length": i(B),
-                     "time_list": f(B, L).zero_(), "timelast_list": f(B, L).zero_(), "target_item_time": f(B).zero_()}
-        self.host = {k: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k, v in self.feed.items()}
+        # feed: ONE arena of 4-byte words at a fixed address (ids, times, Adam hyper-parameters),
+        # so that a step needs one host->device (or device->device) copy and can be replayed
+        # from a captured hipGraph.
+        fields = [("user_id", (B,), torch.int32), ("item_list", (B, L), torch.int32),
+                  ("category_list", (B, L), torch.int32), ("position_list", (B, L), torch.int32),
+                  ("target_item_id", (B,), torch.int32), ("seq_length", (B,), torch.int32),
+                  ("time_list", (B, L), torch.float32), ("timelast_list", (B, L), torch.float32),
+                  ("target_item_time", (B,), torch.float32), ("hyper", (4,), torch.float32)]
+        self.offsets, o = {}, 0
+        for name, shape, dt in fields:
+            n = int(np.prod(shape))
+            self.offsets[name] = (o, n, shape, dt)
+            o += (n + 3) // 4 * 4
+        self.arena = torch.zeros(o, dtype=torch.int32, device=dev)
+        self.host_arena = torch.zeros(o, dtype=torch.int32).pin_memory()
+        self.feed = {name: self._view(self.arena, name) for name in self.offsets}
+        self.host = {name: self._view(self.host_arena, name) for name in self.offsets}
+        self.hyper = self.feed["hyper"]
         # forward activations
         self.ic, self.pos, self.user = f(R, 2 * D), f(R, D), f(B, D)
         self.zr, self.x = f(R, D), f(R, D)
@@ -69,6 +82,12 @@ class _Batch(object):
         self.d_pred = f(B, D)
         self.n_slot = ops.emb_scatter_partials(B, L)
         self.topk_idx = torch.zeros((B, 50), dtype=torch.int32, device=dev)
+
+
+    def _view(self, arena, name):
+        o, n, shape, dt = self.offsets[name]
+        v = arena[o:o + n]
+        return (v.view(torch.float32) if dt == torch.float32 else v).view(*shape)
 
 
 class TimeAwarePath(object):
@@ -110,13 +129,11 @@ class TimeAwarePath(object):
         self.nb_item = ops.sqnorm_blocks(self.tables["item"].numel())
         self.nb_small = [ops.sqnorm_blocks(self.tables[k].numel()) for k in ("category", "position", "user")]
         self.scale = z(2)
-        self.hyper = z(4)
-        self.hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
         self.beta1_power, self.beta2_power = np.float32(0.9), np.float32(0.999)
         self._batches = {}
         self._norm_partials = {}
         self.allreduce_fn = None        # set by data_parallel.attach()
-        self.global_batch = None        # mean divisor across ranks (None: local batch)
+        self.world_size = 1             # the loss is a mean over world_size * B samples
 
     # ----------------------------------------------------------------- helpers
     def seg(self, name, flat=None):
@@ -129,23 +146,33 @@ class TimeAwarePath(object):
             self._norm_partials[B] = torch.zeros(n, dtype=torch.float32, device=self.device)
         return self._batches[B]
 
-    def load_feed(self, feed):
-        """Host feed arrays (Embedding.make_feed_dic_new) -> the fixed device buffers."""
-        B = len(feed["user_id"])
-        bt = self.batch(B)
+    def lr_t(self, lr):
+        """lr placeholder (float64, Model/base_model.py:25) -> Adam's lr_t [TF1.14]:
+        lr * sqrt(1 - beta2^t) / (1 - beta1^t), in float32."""
+        lr32 = np.float32(lr)
+        return lr32 * np.sqrt(np.float32(1) - self.beta2_power) / (np.float32(1) - self.beta1_power)
+
+    def fill_host(self, bt, feed, lr=None):
         for k in INT_FIELDS + FLOAT_FIELDS:
             h = bt.host[k]
             h.copy_(torch.from_numpy(np.ascontiguousarray(feed[k])).to(h.dtype).view(h.shape))
-            bt.feed[k].copy_(h, non_blocking=True)
+        hy = bt.host["hyper"]
+        hy[0] = float(self.lr_t(lr)) if lr is not None else 0.0
+        hy[1], hy[2], hy[3] = 0.9, 0.999, 1e-8
+
+    def load_feed(self, feed, lr=None):
+        """Host feed arrays (Embedding.make_feed_dic_new) [+ learning rate] -> the fixed
+        device arena, one pinned host->device copy."""
+        bt = self.batch(len(feed["user_id"]))
+        self.fill_host(bt, feed, lr)
+        bt.arena.copy_(bt.host_arena, non_blocking=True)
         return bt
 
-    def set_learning_rate(self, lr):
-        """lr placeholder (float64, Model/base_model.py:25) -> Adam's lr_t [TF1.14]."""
-        lr32 = np.float32(lr)
-        lr_t = lr32 * np.sqrt(np.float32(1) - self.beta2_power) / (np.float32(1) - self.beta1_power)
-        self.hyper_host[0] = float(lr_t)
-        self.hyper_host[1], self.hyper_host[2], self.hyper_host[3] = 0.9, 0.999, 1e-8
-        self.hyper.copy_(self.hyper_host, non_blocking=True)
+    def stage(self, feed, lr):
+        """A device-resident copy of one step's arena (bench: inputs already in HBM)."""
+        bt = self.batch(len(feed["user_id"]))
+        self.fill_host(bt, feed, lr)
+        return bt.host_arena.to(self.device, non_blocking=False)
 
     def advance_beta_powers(self):
         self.beta1_power = np.float32(self.beta1_power * np.float32(0.9))
@@ -177,7 +204,7 @@ class TimeAwarePath(object):
 
     def loss_and_logit_grad(self, bt):
         B, V = bt.B, self.item_rows
-        gb = B if self.global_batch is None else self.global_batch
+        gb = B * self.world_size
         # logits -> lse, ce; then d_logits in place
         ops.softmax_ce(bt.logits, V, bt.feed["target_item_id"], B, V, 1.0 / gb, bt.lse, bt.ce, bt.logits,
                        bt.ce_partial)
@@ -254,16 +281,19 @@ class TimeAwarePath(object):
                 o += nb
             n = o
         ops.clip_scale(part, n, self.clip, self.scale)
-        ops.adam(self.params, self.m, self.v, self.grads, self.grads.numel(), self.scale, self.hyper, 0)
+        ops.adam(self.params, self.m, self.v, self.grads, self.grads.numel(), self.scale, bt.hyper, 0)
         for k in ("item", "category", "position", "user"):
             ops.adam(self.tables[k], self.tm[k], self.tv[k], self.g_tab[k], self.tables[k].numel(),
-                     self.scale, self.hyper, 1)
+                     self.scale, bt.hyper, 1)
 
-    def train_kernels(self, bt):
-        """Everything between feed upload and loss read-back; capturable."""
+    def forward_backward_kernels(self, bt):
         self.forward(bt, training=True)
         self.loss_and_logit_grad(bt)
         self.backward(bt)
+
+    def train_kernels(self, bt):
+        """Everything between feed upload and loss read-back; capturable."""
+        self.forward_backward_kernels(bt)
         if self.allreduce_fn is not None:
             self.allreduce_fn(self, bt)
         self.clip_and_apply(bt)

@@ -295,7 +295,7 @@ def train_step(model, arrays, state, feed, lr, num_heads, num_blocks, regulation
         arrays[k] = (arrays[k] - lr_t * state.m[k] / (np.sqrt(state.v[k]) + eps)).astype(np.float32)
     state.beta1_power = np.float32(state.beta1_power * b1)
     state.beta2_power = np.float32(state.beta2_power * b2)
-    return dict(loss=float(out["loss"]), ce_mean=float(out["ce"].mean()), l2=float(out["l2"]),
+    return dict(loss=float(out["loss"].detach()), ce_mean=float(out["ce"].detach().mean()), l2=float(out["l2"].detach()),
                 global_norm=float(norm), scale=float(scale), logits=out["logits"].detach().numpy(),
                 pred=out["pred"].detach().numpy(), grads=grads)
 
