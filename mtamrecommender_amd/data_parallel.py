@@ -35,9 +35,10 @@ def allreduce_gradients(buffers, group=None):
         dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
 
 
-def attach(path, world_size, group=None):
-    """Make ``path.train_kernels`` exchange gradients; call once after building the model."""
-    if world_size <= 1:
+def attach(path, world_size, group=None, force=False):
+    """Make ``path.train_kernels`` exchange gradients; call once after building the model.
+    ``force`` installs the exchange even for one rank (tests the code path on one GPU)."""
+    if world_size <= 1 and not force:
         return
     path.tf_compat = False
     path.world_size = world_size

@@ -1,0 +1,188 @@
+"""Trainer: batch loop, learning-rate schedule, evaluation cadence.
+
+Mirror of the reference's ``Train_main_process`` (train_process.py:34-472) for the
+experiment types the HIP path implements.  Kept semantics:
+
+* learning rate (train_process.py:154-159,324,333-336): every epoch starts from
+  ``FLAGS.learning_rate``; while the current value is > 1e-3 the next one is
+  ``FLAGS.learning_rate * 0.99 ** floor(step / 100)``, otherwise
+  ``1e-3 * FLAGS.decay_rate ** floor(step / 100)`` (tf.train.exponential_decay,
+  staircase) -- with the default learning_rate 1e-3 the second rule always applies;
+* ``random.shuffle(train_set)`` per epoch, sequential ``DataInput`` batches with a
+  short final batch (:321,326);
+* evaluation before training, every ``eval_freq`` global steps and at the end of
+  every epoch (:308,350-362,379); per-batch metrics are averaged UNWEIGHTED over
+  batches (:257-277); best-so-far per K only when both HR and NDCG improve (:279-288);
+* checkpoint at every evaluation point and at the end (:364,403).
+
+Differences: the reference swallows every per-step exception and continues
+(:329-371); here that is opt-in (``FLAGS.swallow_step_errors``).  The reference's
+data adapters are missing from its tree, so records come from the
+synthetic generator unless ``train_set`` / ``test_set`` are handed in.
+"""
+import math
+import random
+import time
+
+import numpy as np
+
+from .config.model_parameter import model_parameter
+from .DataHandle.get_input_data import DataInput
+from .util.model_log import create_log
+
+random.seed(1234)
+np.random.seed(1234)
+
+KS = (1, 5, 10, 30, 50)
+
+
+def exponential_decay(learning_rate, global_step, decay_steps, decay_rate):
+    """tf.train.exponential_decay(staircase=True) [TF1.14]: lr * rate ** floor(step / decay_steps),
+    evaluated in float32 like the TF op."""
+    p = np.float32(math.floor(global_step / decay_steps))
+    return float(np.float32(learning_rate) * np.power(np.float32(decay_rate), p))
+
+
+def next_learning_rate(current, flags_learning_rate, decay_rate, global_step):
+    """One evaluation of the reference's lr1 / lr2 choice (train_process.py:333-336)."""
+    if current > 0.001:
+        return exponential_decay(flags_learning_rate, global_step, 100, 0.99)
+    return exponential_decay(0.001, global_step, 100, decay_rate)
+
+
+def average_metrics(per_batch):
+    """Unweighted mean over batches of the 10-tuples from metrics_topK (train_process.py:257-277)."""
+    if not per_batch:
+        return tuple([0.0] * 10)
+    return tuple(float(np.mean([m[i] for m in per_batch])) for i in range(10))
+
+
+class Train_main_process(object):
+
+    def __init__(self, experiment_name="MTAMb1_movielen", argv=None, train_set=None, test_set=None,
+                 counts=None, device="cuda:0"):
+        start_time = time.time()
+        model_parameter_ins = model_parameter()
+        model_parameter_ins.get_parameter(experiment_name)
+        if argv:
+            model_parameter_ins.parse_argv(argv)
+        self.FLAGS = model_parameter_ins.FLAGS
+        self.logger = create_log(type=self.FLAGS.type, experiment_type=self.FLAGS.experiment_type,
+                                 version=self.FLAGS.version).logger
+        for k, v in self.FLAGS.flag_values_dict().items():
+            self.logger.info("%s: %s" % (k, v))
+        L = self.FLAGS.length_of_user_history
+        if train_set is None:
+            from .data.synthetic import ML1M, SyntheticCatalog, make_records
+            cat = SyntheticCatalog(seed=1234, **ML1M)
+            train_set = make_records(cat, 20000, L, seed=1234)
+            test_set = make_records(cat, 2000, L, seed=4321)
+            counts = dict(user_count=cat.user_count, item_count=cat.item_count,
+                          category_count=cat.category_count)
+        self.train_set, self.test_set = list(train_set), list(test_set)
+        self.user_count, self.item_count, self.category_count = \
+            counts["user_count"], counts["item_count"], counts["category_count"]
+        self.logger.info('Init data finish.\tCost time: %.2fs' % (time.time() - start_time))
+        from .Embedding.Behavior_embedding_time_aware_attention import Behavior_embedding_time_aware_attention
+        self.emb = Behavior_embedding_time_aware_attention(
+            is_training=self.FLAGS.is_training, user_count=self.user_count, item_count=self.item_count,
+            category_count=self.category_count, max_length_seq=L)
+        self.device = device
+        self.global_step = 0
+        self.one_epoch_step = 0
+        self.now_epoch = 0
+        self.best = {k: (0.0, 0.0) for k in KS}
+
+    # ------------------------------------------------------------------ pieces
+    def build_model(self):
+        from .Model.base_model import Session
+        from .Model.MTAMRec_model import MTAM
+        self.sess = Session(self.device)
+        if self.FLAGS.experiment_type == "MTAM":
+            self.model = MTAM(self.FLAGS, self.emb, self.sess)
+        else:
+            raise NotImplementedError("experiment_type %r has no HIP path yet (MTAM only)"
+                                      % self.FLAGS.experiment_type)
+        return self.model
+
+    def eval_topk(self):
+        per_batch = []
+        for _, batch_data in DataInput(self.test_set, self.FLAGS.test_batch_size):
+            per_batch.append(self.model.metrics_topK(sess=self.sess, batch_data=batch_data,
+                                                     global_step=self.global_step, topk=self.FLAGS.top_k))
+        avg = average_metrics(per_batch)
+        for i, k in enumerate(KS):
+            hr, ndcg = avg[2 * i], avg[2 * i + 1]
+            if hr > self.best[k][0] and ndcg > self.best[k][1]:
+                self.best[k] = (hr, ndcg)
+            self.model.train_writer.add_summary({"recall@%d" % k: hr, "ndgc@%d" % k: ndcg}, self.global_step)
+            self.logger.info('Test recall rate @ %d : %.4f   ndcg @ %d: %.4f' % (k, hr, k, ndcg))
+        return avg
+
+    def save_model(self):
+        self.model.save(self.sess, self.global_step)
+
+    # -------------------------------------------------------------------- loop
+    def train(self, max_steps=None):
+        start_time = time.time()
+        self.build_model()
+        self.logger.info('Init finish.\tCost time: %.2fs' % (time.time() - start_time))
+        test_start = time.time()
+        self.eval_topk()
+        self.logger.info('End test. \tTest Cost time: %.2fs' % (time.time() - test_start))
+        self.logger.info('Training....\tmax_epochs:%d\tepoch_size:%d'
+                         % (self.FLAGS.max_epochs, self.FLAGS.train_batch_size))
+        start_time, avg_loss, step_loss = time.time(), 0.0, float("nan")
+        for epoch in range(self.FLAGS.max_epochs):
+            random.shuffle(self.train_set)
+            self.logger.info('tain_set:%d' % len(self.train_set))
+            epoch_start_time = time.time()
+            learning_rate = self.FLAGS.learning_rate
+            for step_i, train_batch_data in DataInput(self.train_set, self.FLAGS.train_batch_size):
+                try:
+                    learning_rate = next_learning_rate(learning_rate, self.FLAGS.learning_rate,
+                                                       self.FLAGS.decay_rate, self.global_step)
+                    add_summary = bool(self.global_step % self.FLAGS.display_freq == 0)
+                    step_loss, merge = self.model.train(self.sess, train_batch_data, learning_rate,
+                                                        add_summary, self.global_step, epoch)
+                    self.model.train_writer.add_summary(merge, self.global_step)
+                    avg_loss = avg_loss + step_loss
+                    self.global_step = self.global_step + 1
+                    self.one_epoch_step = self.one_epoch_step + 1
+                    if self.global_step % self.FLAGS.eval_freq == 0:
+                        self.logger.info("Epoch step is " + str(self.one_epoch_step))
+                        self.logger.info("Global step is " + str(self.global_step))
+                        self.logger.info("Train_loss is " + str(avg_loss / self.FLAGS.eval_freq))
+                        self.eval_topk()
+                        avg_loss = 0
+                        self.save_model()
+                except Exception as e:
+                    if not self.FLAGS.swallow_step_errors:
+                        raise
+                    self.logger.info("Error in training step")
+                    self.logger.info(e)
+                if max_steps is not None and self.global_step >= max_steps:
+                    break
+            self.logger.info('one epoch Cost time: %.2f' % (time.time() - epoch_start_time))
+            self.logger.info("Global step is " + str(self.global_step))
+            self.logger.info("Train_loss is " + str(step_loss))
+            self.eval_topk()
+            for k in KS:
+                self.logger.info('Max recall rate @ %d: %.4f   ndcg @ %d: %.4f' % (k, self.best[k][0], k, self.best[k][1]))
+            self.one_epoch_step = 0
+            self.logger.info('Epoch %d DONE\tCost time: %.2f' % (self.now_epoch, time.time() - start_time))
+            self.now_epoch = self.now_epoch + 1
+            if max_steps is not None and self.global_step >= max_steps:
+                break
+        self.model.save(self.sess, self.global_step)
+        self.logger.info('Finished')
+
+
+if __name__ == '__main__':
+    import sys
+    name = "MTAMb1_movielen"
+    argv = sys.argv[1:]
+    if argv and not argv[0].startswith("--"):
+        name, argv = argv[0], argv[1:]
+    main_process = Train_main_process(name, argv)
+    main_process.train()

@@ -1,0 +1,77 @@
+"""Generates tests/golden/mtam_*.npz from the CPU oracle.
+
+PARITY UNPINNED: the reference has no golden vectors and TensorFlow 1.14 cannot
+run here, so these fixtures come from this repo's own oracle
+(oracle/mtam_oracle.py, float64), cross-checked against oracle/numpy_ref.py when
+they are made.  They pin the oracle against regressions and travel to the GPU
+box, where the HIP path is compared with them.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from mtamrecommender_amd.data.synthetic import SyntheticCatalog, make_records  # noqa: E402
+from mtamrecommender_amd.Embedding.feed import pad_batch  # noqa: E402
+from mtamrecommender_amd.Model.variables import init_variables, model_specs  # noqa: E402
+from oracle import mtam_oracle as O, numpy_ref as N  # noqa: E402
+
+CASES = {
+    # name: (model, B, L, D, NB, H, items, cats, users, seed)
+    "mtam_b6_l8_nb2_h2": ("MTAM", 6, 8, 128, 2, 2, 90, 7, 25, 11),
+    "mtam_b16_l50_nb1_h1": ("MTAM", 16, 50, 128, 1, 1, 300, 17, 40, 12),
+    "pistrec_b5_l10_nb2_h1": ("PISTRec", 5, 10, 128, 2, 1, 80, 6, 20, 13),
+}
+REG = 5e-5
+
+
+def make_case(model, B, L, D, NB, H, items, cats, users, seed):
+    cat = SyntheticCatalog(items, cats, users, seed=seed)
+    records = make_records(cat, B, L, seed=seed + 1)
+    feed = pad_batch(records, L)
+    specs = model_specs(model, users, items, cats, L, D, NB)
+    arrays = init_variables(specs, seed=seed + 2)
+    rng = np.random.default_rng(seed + 3)
+    for k, v in arrays.items():                      # non-trivial biases / LN scales
+        if v.ndim == 1 or v.shape[0] == 1:
+            arrays[k] = (v + rng.normal(0, 0.05, v.shape)).astype(np.float32)
+    return records, feed, arrays
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name, (model, B, L, D, NB, H, items, cats, users, seed) in CASES.items():
+        records, feed, arrays = make_case(model, B, L, D, NB, H, items, cats, users, seed)
+        out, grads, slot_sq = O.loss_and_grads(model, arrays, feed, H, NB, REG, torch.float64)
+        ref = N.forward(model, arrays, feed, H, NB, REG)
+        assert np.abs(out["logits"].detach().numpy() - ref["logits"]).max() < 1e-10
+        logits = out["logits"].detach().numpy()
+        payload = {"feed_" + k: v for k, v in feed.items()}
+        payload.update({
+            "weights_checksum": np.array([float(sum(np.abs(v.astype(np.float64)).sum() for v in arrays.values()))]),
+            "logits": logits.astype(np.float64),
+            "pred": out["pred"].detach().numpy(),
+            "loss": np.array([float(out["loss"].detach())]),
+            "l2": np.array([float(out["l2"].detach())]),
+            "ce": out["ce"].detach().numpy(),
+            "top50": O.top_k(logits, min(50, logits.shape[1])),
+            "global_norm_tf": np.array([O.global_norm(grads, slot_sq, model, True)]),
+            "global_norm_true": np.array([O.global_norm(grads, slot_sq, model, False)]),
+        })
+        for k, g in grads.items():
+            if g is not None and g.size <= 4096:                     # small tensors whole, large ones by norm
+                payload["grad/" + k] = g
+            elif g is not None:
+                payload["gradnorm/" + k] = np.array([np.sqrt((g.astype(np.float64) ** 2).sum())])
+        np.savez_compressed(os.path.join(here, name + ".npz"), **payload)
+        print(name, "loss", payload["loss"][0], "bytes", os.path.getsize(os.path.join(here, name + ".npz")))
+
+
+if __name__ == "__main__":
+    main()
