@@ -74,8 +74,27 @@ int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
                   const float *aux_in, float *aux_out, int ld_aux,
                   int split_k, void *stream);
 
+/* Grouped weight-gradient GEMMs: n <= MTAM_MAX_GROUP independent problems
+ * C[M,N] += A^T B with A [K,M] (lda), B [K,N] (ldb), split-K slices added by
+ * atomics, all in ONE launch (the dW of every dense layer after backward;
+ * tf.gradients w.r.t. the kernels, Model/base_model.py:292).  `d` is a HOST array. */
+#define MTAM_MAX_GROUP 16
+typedef struct {
+  const float *A; int lda;
+  const float *B; int ldb;
+  float *C; int ldc;
+  int M, N, K, split_k;
+} MtamGemmDesc;
+int mtam_gemm_tn_atomic_grouped(int n, const MtamGemmDesc *d, void *stream);
+
 /* column sums: out[c] += sum_r in[r, c]  (atomicAdd; bias gradients) */
 int mtam_colsum_atomic(const float *in, int rows, int cols, int ld, float *out, void *stream);
+/* the same for n <= MTAM_MAX_GROUP jobs in one launch; `jobs` is a HOST array */
+typedef struct {
+  const float *in; int rows, cols, ld;
+  float *out;
+} MtamColsumJob;
+int mtam_colsum_atomic_multi(int n, const MtamColsumJob *jobs, void *stream);
 
 /* --------------------------------------------------------- embedding gather
  * tf.nn.embedding_lookup x4 (Embedding/Behavior_embedding_time_aware_attention.py:68,75,82,90)
@@ -232,18 +251,25 @@ int mtam_topk(const float *scores, int ld, int rows, int V, int k,
  * mtam_sqnorm_partial: partial[i] = per-block sum of g^2 over n floats;
  *   needs mtam_sqnorm_blocks(n) floats.
  * mtam_clip_scale: scale[0] = clip * min(1/norm, 1/clip), scale[1] = norm, with
- *   norm = sqrt(sum of all partials).
+ *   norm = sqrt(sum of all partials).  With lr / adam_state given it also does
+ *   Adam's per-step bookkeeping on the device (so a captured step needs no host
+ *   arithmetic): adam_state [8] = {lr_t, beta1, beta2, eps, beta1_power,
+ *   beta2_power, -, -}; lr_t = lr[0]*sqrt(1-beta2_power)/(1-beta1_power) is
+ *   written from the CURRENT powers, which are then multiplied by beta1/beta2
+ *   (AdamOptimizer._prepare/_finish; powers start at beta1, beta2).
  * mtam_adam: p, m, v updated from g * scale[0]; hyper [4] (device) =
- *   lr_t, beta1, beta2, eps with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) formed by the caller.
- *   sparse_form != 0: m = m*b1 + g*(1-b1) (IndexedSlices path, tables);
- *   else m += (g-m)*(1-b1) (dense ApplyAdam kernel).
+ *   lr_t, beta1, beta2, eps (= the head of adam_state).  Elements at index >=
+ *   sparse_begin use m = m*b1 + g*(1-b1) (IndexedSlices path, tables); the ones
+ *   before it m += (g-m)*(1-b1) (dense ApplyAdam kernel).  sparse_begin must be a
+ *   multiple of mtam_adam_block() (or >= n: all dense; 0: all tables).
  */
 int mtam_sqnorm_blocks(size_t n);
 int mtam_sqnorm_partial(const float *g, size_t n, float *partial, void *stream);
 int mtam_clip_scale(const float *partials, int n_partials, float clip_norm, float *scale,
-                    void *stream);
+                    const float *lr, float *adam_state, void *stream);
+int mtam_adam_block(void);
 int mtam_adam(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
-              const float *hyper, int sparse_form, void *stream);
+              const float *hyper, size_t sparse_begin, void *stream);
 
 #ifdef __cplusplus
 }

@@ -117,9 +117,7 @@ class base_model(object):
                  "tables": {k: v.detach().cpu() for k, v in p.tables.items()},
                  "dense": {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.dense_tf().items()},
                  "dead": {k: torch.from_numpy(v) for k, v in self.dead_variables.items()},
-                 "adam": {"m": p.m.cpu(), "v": p.v.cpu(), "tm": {k: v.cpu() for k, v in p.tm.items()},
-                          "tv": {k: v.cpu() for k, v in p.tv.items()},
-                          "beta1_power": float(p.beta1_power), "beta2_power": float(p.beta2_power)}}
+                 "adam": p.optimizer_state()}
         if variable_list is not None:
             state["dense"] = {k: v for k, v in state["dense"].items() if k in variable_list}
         torch.save(state, save_path)
@@ -140,11 +138,7 @@ class base_model(object):
                 dense[k] = v.numpy()
         p.params.copy_(torch.from_numpy(p.layout.pack(dense)))
         if variable_list is None and "adam" in state:
-            a = state["adam"]
-            p.m.copy_(a["m"]); p.v.copy_(a["v"])
-            for k in p.tm:
-                p.tm[k].copy_(a["tm"][k]); p.tv[k].copy_(a["tv"][k])
-            p.beta1_power, p.beta2_power = np.float32(a["beta1_power"]), np.float32(a["beta2_power"])
+            p.load_optimizer_state(state["adam"])
         self.logger.info('model restored from %s' % path)
 
     # ------------------------------------------------------------------ step
@@ -177,7 +171,6 @@ class base_model(object):
             self._run("train_fb", bt, p.forward_backward_kernels)
             p.allreduce_fn(p, bt)
             self._run("train_up", bt, p.clip_and_apply)
-        p.advance_beta_powers()
 
     def train(self, sess, batch_data, learning_rate, add_summary=False, global_step=0, epoch=0):
         """One optimizer step on one batch -> (loss, summary) (reference :150-167)."""

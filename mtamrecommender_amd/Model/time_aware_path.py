@@ -7,15 +7,19 @@ fixed sequence of ``mtam_*`` launches over pre-allocated HBM buffers:
   forward   gather -> dense4emb GEMM -> x-projection GEMM -> time-aware GRU
             -> K/V GEMM -> NB decoder blocks -> head LN -> logits GEMM
             -> softmax CE                                   
-  backward  the same chain reversed, weight gradients by split-K GEMMs,
-            embedding rows by atomic scatter-add                     (K11)
-  update    global-norm clip -> Adam on the flat dense buffer and on the four
-            tables                                                (K12, K13)
+  backward  the same chain reversed; every weight gradient in ONE grouped
+            split-K GEMM launch, every bias-like gradient in ONE column-sum
+            launch, embedding rows by atomic scatter-add             (K11)
+  update    global-norm clip -> ONE Adam launch over the flat parameter space
+            (dense variables and the four tables)                 (K12, K13)
 
-Nothing is allocated inside a step, so a step can be captured into a hipGraph
-(``torch.cuda.CUDAGraph``) and replayed; dynamic inputs live in fixed device
-buffers that ``load_feed`` overwrites.  Data-parallel training calls
-``allreduce_fn`` between backward and update (see ``data_parallel.py``).
+All trainable state lives in one flat float32 space
+``[dense | pad | category | position | user | item]`` (parameters, gradients,
+Adam m and v share the layout).  Nothing is allocated inside a step and Adam's
+per-step scalars are kept on the device, so a step is captured once into a
+hipGraph (``torch.cuda.CUDAGraph``) and replayed; the only per-step input is
+the feed arena.  Data-parallel training calls ``allreduce_fn`` between
+backward and update (``data_parallel.py``).
 """
 import numpy as np
 import torch
@@ -26,6 +30,13 @@ from .param_layout import DenseLayout
 D = 128
 INT_FIELDS = ("user_id", "item_list", "category_list", "position_list", "target_item_id", "seq_length")
 FLOAT_FIELDS = ("time_list", "timelast_list", "target_item_time")
+TABLES = ("category", "position", "user", "item")        # order inside the flat space (item last)
+MAX_GROUP = 16
+
+
+def _chunks(seq, n):
+    for i in range(0, len(seq), n):
+        yield seq[i:i + n]
 
 
 class _Batch(object):
@@ -36,16 +47,14 @@ class _Batch(object):
         R = B * L
         V = path.item_rows
         f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        i = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)
         self.B, self.R = B, R
-        # feed: ONE arena of 4-byte words at a fixed address (ids, times, Adam hyper-parameters),
-        # so that a step needs one host->device (or device->device) copy and can be replayed
-        # from a captured hipGraph.
+        # feed: ONE arena of 4-byte words at a fixed address (ids, times, learning rate), so that a
+        # step needs one host->device (or device->device) copy and can be replayed from a hipGraph.
         fields = [("user_id", (B,), torch.int32), ("item_list", (B, L), torch.int32),
                   ("category_list", (B, L), torch.int32), ("position_list", (B, L), torch.int32),
                   ("target_item_id", (B,), torch.int32), ("seq_length", (B,), torch.int32),
                   ("time_list", (B, L), torch.float32), ("timelast_list", (B, L), torch.float32),
-                  ("target_item_time", (B,), torch.float32), ("hyper", (4,), torch.float32)]
+                  ("target_item_time", (B,), torch.float32), ("lr", (4,), torch.float32)]
         self.offsets, o = {}, 0
         for name, shape, dt in fields:
             n = int(np.prod(shape))
@@ -55,7 +64,6 @@ class _Batch(object):
         self.host_arena = torch.zeros(o, dtype=torch.int32).pin_memory()
         self.feed = {name: self._view(self.arena, name) for name in self.offsets}
         self.host = {name: self._view(self.host_arena, name) for name in self.offsets}
-        self.hyper = self.feed["hyper"]
         # forward activations
         self.ic, self.pos, self.user = f(R, 2 * D), f(R, D), f(B, D)
         self.zr, self.x = f(R, D), f(R, D)
@@ -74,15 +82,16 @@ class _Batch(object):
         self.d_dec = [f(B, D) for _ in range(NB + 1)]
         self.d_kv = f(R, 2 * NB * D)
         self.d_x, self.d_z = f(R, D), f(R, D)
-        self.d_qt = f(B, 2 * D)
-        self.d_tp_partial, self.d_ln_partial = f(B, 5 * L), f(B, 2 * D)
+        self.d_qt = [f(B, 2 * D) for _ in range(NB)]
+        self.d_tp_partial = [f(B, 5 * L) for _ in range(NB)]
+        self.d_ln_partial = [f(B, 2 * D) for _ in range(NB)]
         self.d_xproj, self.rh = f(R, 3 * D), f(R, D)
         self.d_tvec_partial = f(B, 8 * D)
         self.d_ic = f(R, 2 * D)
         self.d_pred = f(B, D)
         self.n_slot = ops.emb_scatter_partials(B, L)
+        self.norm_partial = torch.zeros(path.nb_all + self.n_slot, dtype=torch.float32, device=dev)
         self.topk_idx = torch.zeros((B, 50), dtype=torch.int32, device=dev)
-
 
     def _view(self, arena, name):
         o, n, shape, dt = self.offsets[name]
@@ -95,43 +104,48 @@ class TimeAwarePath(object):
 
     def __init__(self, tables, dense_tf, L, num_heads, num_blocks, regulation_rate, max_gradient_norm,
                  tf_compat_global_norm=True, device="cuda:0"):
-        self.device = torch.device(device)
+        self.device = dev = torch.device(device)
         self.L, self.H, self.NB = L, num_heads, num_blocks
         self.reg, self.clip = float(regulation_rate), float(max_gradient_norm)
         self.tf_compat = bool(tf_compat_global_norm)
         self.layout = DenseLayout("MTAM", D, L, num_blocks)
-        dev = self.device
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
-        # tables: "user", "item", "category", "position"
-        self.tables = {k: t(v) for k, v in tables.items()}
-        for k, v in self.tables.items():
+        for k, v in tables.items():
             if v.shape[1] != D:
                 raise ValueError("this build supports num_units == %d only (table %s has %d)" % (D, k, v.shape[1]))
-        self.item_rows = self.tables["item"].shape[0]
-        self.params = t(self.layout.pack(dense_tf))
+        # ---- flat parameter space: [dense | pad to the Adam block | category | position | user | item]
         P = self.layout.total
+        blk = ops.adam_block()
+        self.n_dense = (P + blk - 1) // blk * blk
+        self.tab_off, o = {}, self.n_dense
+        for k in TABLES:
+            self.tab_off[k] = o
+            o += int(tables[k].size)
+        self.n_total = o
+        self.item_rows = tables["item"].shape[0]
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
-        self.m, self.v = z(P), z(P)
-        self.tm = {k: torch.zeros_like(v) for k, v in self.tables.items()}
-        self.tv = {k: torch.zeros_like(v) for k, v in self.tables.items()}
-        # one zeroed-per-step arena: dense gradients + the three small table gradients
-        sizes = [P] + [self.tables[k].numel() for k in ("category", "position", "user")]
-        self.zero_arena = z(sum(sizes))
-        o = 0
-        self.grads = self.zero_arena[o:o + P]; o += P
-        self.g_tab = {}
-        for k in ("category", "position", "user"):
-            n = self.tables[k].numel()
-            self.g_tab[k] = self.zero_arena[o:o + n].view_as(self.tables[k]); o += n
-        self.g_tab["item"] = torch.empty_like(self.tables["item"])
-        # global-norm partial sums: [dense | item dense | slots or small tables]
-        self.nb_dense = ops.sqnorm_blocks(P)
+        self.flat_p, self.flat_g, self.flat_m, self.flat_v = z(o), z(o), z(o), z(o)
+        self.params = self.flat_p[:P]
+        self.grads = self.flat_g[:P]
+        self.m, self.v = self.flat_m[:P], self.flat_v[:P]
+        tview = lambda flat, k: flat[self.tab_off[k]:self.tab_off[k] + tables[k].size].view(*tables[k].shape)
+        self.tables = {k: tview(self.flat_p, k) for k in TABLES}
+        self.g_tab = {k: tview(self.flat_g, k) for k in TABLES}
+        self.tm = {k: tview(self.flat_m, k) for k in TABLES}
+        self.tv = {k: tview(self.flat_v, k) for k in TABLES}
+        self.params.copy_(torch.from_numpy(self.layout.pack(dense_tf)))
+        for k in TABLES:
+            self.tables[k].copy_(torch.from_numpy(np.ascontiguousarray(tables[k], dtype=np.float32)))
+        # everything before the item gradient is zeroed per step (the item gradient is overwritten
+        # by the dense scoring GEMM)
+        self.zero_prefix = self.flat_g[:self.tab_off["item"]]
+        self.nb_dense = ops.sqnorm_blocks(self.n_dense)
         self.nb_item = ops.sqnorm_blocks(self.tables["item"].numel())
-        self.nb_small = [ops.sqnorm_blocks(self.tables[k].numel()) for k in ("category", "position", "user")]
+        self.nb_all = max(ops.sqnorm_blocks(self.n_total), self.nb_dense + self.nb_item)
         self.scale = z(2)
-        self.beta1_power, self.beta2_power = np.float32(0.9), np.float32(0.999)
+        # Adam state on the device: [lr_t, beta1, beta2, eps, beta1_power, beta2_power, -, -]
+        self.adam_state = torch.tensor([0.0, 0.9, 0.999, 1e-8, 0.9, 0.999, 0.0, 0.0], dtype=torch.float32,
+                                       device=dev)
         self._batches = {}
-        self._norm_partials = {}
         self.allreduce_fn = None        # set by data_parallel.attach()
         self.world_size = 1             # the loss is a mean over world_size * B samples
 
@@ -142,23 +156,13 @@ class TimeAwarePath(object):
     def batch(self, B):
         if B not in self._batches:
             self._batches[B] = _Batch(self, B)
-            n = self.nb_dense + self.nb_item + max(self._batches[B].n_slot, sum(self.nb_small))
-            self._norm_partials[B] = torch.zeros(n, dtype=torch.float32, device=self.device)
         return self._batches[B]
-
-    def lr_t(self, lr):
-        """lr placeholder (float64, Model/base_model.py:25) -> Adam's lr_t [TF1.14]:
-        lr * sqrt(1 - beta2^t) / (1 - beta1^t), in float32."""
-        lr32 = np.float32(lr)
-        return lr32 * np.sqrt(np.float32(1) - self.beta2_power) / (np.float32(1) - self.beta1_power)
 
     def fill_host(self, bt, feed, lr=None):
         for k in INT_FIELDS + FLOAT_FIELDS:
             h = bt.host[k]
             h.copy_(torch.from_numpy(np.ascontiguousarray(feed[k])).to(h.dtype).view(h.shape))
-        hy = bt.host["hyper"]
-        hy[0] = float(self.lr_t(lr)) if lr is not None else 0.0
-        hy[1], hy[2], hy[3] = 0.9, 0.999, 1e-8
+        bt.host["lr"][0] = float(np.float32(lr)) if lr is not None else 0.0   # f64 placeholder cast to f32
 
     def load_feed(self, feed, lr=None):
         """Host feed arrays (Embedding.make_feed_dic_new) [+ learning rate] -> the fixed
@@ -173,10 +177,6 @@ class TimeAwarePath(object):
         bt = self.batch(len(feed["user_id"]))
         self.fill_host(bt, feed, lr)
         return bt.host_arena.to(self.device, non_blocking=False)
-
-    def advance_beta_powers(self):
-        self.beta1_power = np.float32(self.beta1_power * np.float32(0.9))
-        self.beta2_power = np.float32(self.beta2_power * np.float32(0.999))
 
     # ----------------------------------------------------------------- forward
     def forward(self, bt, training=True):
@@ -215,49 +215,56 @@ class TimeAwarePath(object):
         B, R, L, NB, H = bt.B, bt.R, self.L, self.NB, self.H
         fd, T, G = bt.feed, self.tables, self.grads
         gseg = lambda name: self.layout.view(G, name)
-        part = self._norm_partials[B]
-        self.zero_arena.zero_()
+        part = bt.norm_partial
+        self.zero_prefix.zero_()
         # scoring: dE = G^T pred (dense, every row), d_pred = G E
         ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
         if self.tf_compat:
             ops.sqnorm_partial(self.g_tab["item"], self.g_tab["item"].numel(), part[self.nb_dense:])
         bt.d_pred.zero_()
-        split_v = max(1, min(64, self.item_rows // 512))
+        split_v = max(1, min(64, (self.item_rows + 127) // 128))
         ops.gemm(bt.logits, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v)
         ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_dec[NB], gseg("head/ln"))
-        split_r = max(1, min(32, R // 256))
         for i in reversed(range(NB)):
             ln = self.seg("blk%d/ln" % i)
             ops.ta_attn_decode_bwd(bt.d_dec[i + 1], bt.dec[i], bt.x, bt.kv, 2 * NB * D, 2 * i * D,
                                    (2 * i + 1) * D, fd["target_item_time"], fd["time_list"],
                                    fd["seq_length"], self.seg("blk%d/wqt" % i), self.seg("blk%d/tparams" % i),
                                    ln[1], bt.attn_save[i], B, L, H, 0 if i == NB - 1 else 1,
-                                   bt.d_dec[i], bt.d_kv, bt.d_x, bt.d_qt, bt.d_tp_partial, bt.d_ln_partial)
-            ops.gemm(bt.dec[i], bt.d_qt, gseg("blk%d/wqt" % i), trans_a=True)
-            ops.colsum_atomic(bt.d_qt, gseg("blk%d/bq" % i), rows=B, cols=D, ld=2 * D)
-            ops.colsum_atomic(bt.d_tp_partial, gseg("blk%d/tparams" % i).view(-1))
-            ops.colsum_atomic(bt.d_ln_partial, gseg("blk%d/ln" % i).view(-1))
-        # keys/values: d_x += d_kv . Wkv^T ; dWkv, dbkv
+                                   bt.d_dec[i], bt.d_kv, bt.d_x, bt.d_qt[i], bt.d_tp_partial[i],
+                                   bt.d_ln_partial[i])
+        # keys/values: d_x += d_kv . Wkv^T
         ops.gemm(bt.d_kv, self.seg("kv/w"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM)
-        ops.gemm(bt.x, bt.d_kv, gseg("kv/w"), trans_a=True, epilogue=ops.EPI_ATOMIC, split_k=split_r)
-        ops.colsum_atomic(bt.d_kv, gseg("kv/b"))
-        # GRU
+        # GRU back through time, then d_x += d_xproj . Wx^T and d_z = d_x masked by relu(z) > 0
         ops.tagru_bwd(bt.d_dec[0], bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
                       self.seg("gru/wh_c"), self.seg("gru/tvec"), bt.gru_save, B, L, bt.d_xproj, bt.rh,
                       bt.d_x, bt.d_tvec_partial)
-        ops.colsum_atomic(bt.d_tvec_partial, gseg("gru/tvec").view(-1))
         ops.gemm(bt.d_xproj, self.seg("gru/wx"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM_MASK,
                  aux_in=bt.zr, aux_out=bt.d_z)
-        ops.gemm(bt.x, bt.d_xproj, gseg("gru/wx"), trans_a=True, epilogue=ops.EPI_ATOMIC, split_k=split_r)
-        ops.colsum_atomic(bt.d_xproj, gseg("gru/bx"))
-        hprev = bt.gru_save.view(-1)[4 * D:]
-        ops.gemm(hprev, bt.d_xproj, gseg("gru/wh_g"), trans_a=True, epilogue=ops.EPI_ATOMIC, split_k=split_r,
-                 M=D, N=2 * D, K=R, lda=5 * D, ldb=3 * D, ldc=2 * D)
-        ops.gemm(bt.rh, bt.d_xproj.view(-1)[2 * D:], gseg("gru/wh_c"), trans_a=True, epilogue=ops.EPI_ATOMIC,
-                 split_k=split_r, M=D, N=D, K=R, lda=D, ldb=3 * D, ldc=D)
-        # dense4emb
         ops.gemm(bt.d_z, self.seg("dense4emb/w"), bt.d_ic, trans_b=True)
-        ops.gemm(bt.ic, bt.d_z, gseg("dense4emb/w"), trans_a=True, epilogue=ops.EPI_ATOMIC, split_k=split_r)
+        # every weight gradient dW = A^T B in one grouped split-K launch
+        sr = max(1, min(16, R // 256))
+        prob = lambda A, lda, Bm, ldb, name, M, N, K, s: dict(A=A, lda=lda, B=Bm, ldb=ldb, C=gseg(name),
+                                                              ldc=N, M=M, N=N, K=K, split_k=s)
+        problems = [
+            prob(bt.x, D, bt.d_xproj, 3 * D, "gru/wx", D, 3 * D, R, sr),
+            prob(bt.x, D, bt.d_kv, 2 * NB * D, "kv/w", D, 2 * NB * D, R, sr),
+            prob(bt.ic, 2 * D, bt.d_z, D, "dense4emb/w", 2 * D, D, R, sr),
+            prob(bt.gru_save.view(-1)[4 * D:], 5 * D, bt.d_xproj, 3 * D, "gru/wh_g", D, 2 * D, R, sr),
+            prob(bt.rh, D, bt.d_xproj.view(-1)[2 * D:], 3 * D, "gru/wh_c", D, D, R, sr),
+        ] + [prob(bt.dec[i], D, bt.d_qt[i], 2 * D, "blk%d/wqt" % i, D, 2 * D, B, 1) for i in range(NB)]
+        for chunk in _chunks(problems, MAX_GROUP):
+            ops.gemm_tn_atomic_grouped(chunk)
+        # every bias-like gradient (column sums of per-row / per-sample partials) in one launch
+        jobs = [(bt.d_xproj, R, 3 * D, 3 * D, gseg("gru/bx")),
+                (bt.d_kv, R, 2 * NB * D, 2 * NB * D, gseg("kv/b")),
+                (bt.d_tvec_partial, B, 8 * D, 8 * D, gseg("gru/tvec").view(-1))]
+        for i in range(NB):
+            jobs += [(bt.d_qt[i], B, D, 2 * D, gseg("blk%d/bq" % i)),
+                     (bt.d_tp_partial[i], B, 5 * L, 5 * L, gseg("blk%d/tparams" % i).view(-1)),
+                     (bt.d_ln_partial[i], B, 2 * D, 2 * D, gseg("blk%d/ln" % i).view(-1))]
+        for chunk in _chunks(jobs, MAX_GROUP):
+            ops.colsum_atomic_multi(chunk)
         # tables
         slot_part = part[self.nb_dense + self.nb_item:]
         ops.emb_scatter_add_bwd(bt.d_ic, bt.d_x, bt.ic, bt.pos, bt.user, fd["item_list"], fd["category_list"],
@@ -267,24 +274,17 @@ class TimeAwarePath(object):
 
     # ------------------------------------------------------------------ update
     def clip_and_apply(self, bt):
-        B = bt.B
-        part = self._norm_partials[B]
-        ops.sqnorm_partial(self.grads, self.grads.numel(), part)
+        part = bt.norm_partial
         if self.tf_compat:
+            # dense variables + [item dense (measured before the scatter) + un-deduplicated slots]
+            ops.sqnorm_partial(self.flat_g, self.n_dense, part)
             n = self.nb_dense + self.nb_item + bt.n_slot
         else:
-            o = self.nb_dense
-            ops.sqnorm_partial(self.g_tab["item"], self.g_tab["item"].numel(), part[o:])
-            o += self.nb_item
-            for k, nb in zip(("category", "position", "user"), self.nb_small):
-                ops.sqnorm_partial(self.g_tab[k], self.g_tab[k].numel(), part[o:])
-                o += nb
-            n = o
-        ops.clip_scale(part, n, self.clip, self.scale)
-        ops.adam(self.params, self.m, self.v, self.grads, self.grads.numel(), self.scale, bt.hyper, 0)
-        for k in ("item", "category", "position", "user"):
-            ops.adam(self.tables[k], self.tm[k], self.tv[k], self.g_tab[k], self.tables[k].numel(),
-                     self.scale, bt.hyper, 1)
+            ops.sqnorm_partial(self.flat_g, self.n_total, part)
+            n = ops.sqnorm_blocks(self.n_total)
+        ops.clip_scale(part, n, self.clip, self.scale, bt.feed["lr"], self.adam_state)
+        ops.adam(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,
+                 self.adam_state, self.n_dense)
 
     def forward_backward_kernels(self, bt):
         self.forward(bt, training=True)
@@ -308,9 +308,17 @@ class TimeAwarePath(object):
 
     def grads_tf(self):
         out = self.layout.unpack(self.grads.detach().cpu().numpy())
-        for k in ("user", "item", "category", "position"):
+        for k in TABLES:
             out["embedding_layer/" + k] = self.g_tab[k].detach().cpu().numpy()
         return out
 
     def tables_numpy(self):
         return {k: v.detach().cpu().numpy() for k, v in self.tables.items()}
+
+    def optimizer_state(self):
+        return {"flat_m": self.flat_m.cpu(), "flat_v": self.flat_v.cpu(), "adam_state": self.adam_state.cpu()}
+
+    def load_optimizer_state(self, st):
+        self.flat_m.copy_(st["flat_m"])
+        self.flat_v.copy_(st["flat_v"])
+        self.adam_state.copy_(st["adam_state"])

@@ -42,9 +42,23 @@ SIGNATURES = {
     "mtam_topk": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     "mtam_sqnorm_blocks": (c_int, [c_size_t]),
     "mtam_sqnorm_partial": (c_int, [P, c_size_t, P, P]),
-    "mtam_clip_scale": (c_int, [P, c_int, c_float, P, P]),
-    "mtam_adam": (c_int, [P, P, P, P, c_size_t, P, P, c_int, P]),
+    "mtam_clip_scale": (c_int, [P, c_int, c_float, P, P, P, P]),
+    "mtam_adam_block": (c_int, []),
+    "mtam_adam": (c_int, [P, P, P, P, c_size_t, P, P, c_size_t, P]),
+    "mtam_gemm_tn_atomic_grouped": (c_int, [c_int, P, P]),
+    "mtam_colsum_atomic_multi": (c_int, [c_int, P, P]),
 }
+
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p),
+                ("ldc", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("split_k", c_int)]
+
+
+class ColsumJob(ctypes.Structure):
+    _fields_ = [("in_", c_void_p), ("rows", c_int), ("cols", c_int), ("ld", c_int), ("out", c_void_p)]
+
 
 _lib = None
 

@@ -105,18 +105,15 @@ __device__ __forceinline__ void store_ccontig(float *__restrict__ S, const float
 }
 
 template <bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float As[BK * LDM];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDM];
+__device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *Bs, int tile, int kslice) {
   constexpr int LDA_S = TA ? LDM : LDK;
   constexpr int LDB_S = TB ? LDK : LDM;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // 1-D tile index (grid.y is capped at 65535; V/64 is not), split-K slice on grid.y
-  const int m0 = (blockIdx.x / p.tiles_n) * BM, n0 = (blockIdx.x % p.tiles_n) * BN;
-  const int kbeg = blockIdx.y * p.k_chunk;
+  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  const int kbeg = kslice * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
 
   f32x16 acc;
@@ -193,6 +190,34 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
   }
 }
 
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float As[BK * LDM];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDM];
+  // 1-D tile index (grid.y is capped at 65535; V/64 is not), split-K slice on grid.y
+  gemm_tile<TA, TB, EPI>(p, As, Bs, blockIdx.x, blockIdx.y);
+}
+
+// Grouped weight-gradient form: up to MTAM_MAX_GROUP independent C += A^T B problems
+// (TA, !TB, atomic epilogue) in ONE launch.  blockIdx.x walks the concatenation of every
+// problem's (tile, k-slice) list; `first[g]` is the prefix sum of block counts.
+struct GroupArgs {
+  GemmArgs g[MTAM_MAX_GROUP];
+  int first[MTAM_MAX_GROUP + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_atomic_grouped_kernel(GroupArgs ga) {
+  __shared__ __attribute__((aligned(16))) float As[BK * LDM];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDM];
+  int g = 0;
+  while (g + 1 < ga.n && (int)blockIdx.x >= ga.first[g + 1]) ++g;
+  const GemmArgs &p = ga.g[g];
+  const int local = blockIdx.x - ga.first[g];
+  const int tiles = p.tiles_n * ((p.M + BM - 1) / BM);
+  gemm_tile<true, false, MTAM_EPI_ATOMIC>(p, As, Bs, local % tiles, local / tiles);
+}
+
 template <bool TA, bool TB>
 void launch_epi(int epi, dim3 grid, hipStream_t s, const GemmArgs &a) {
   switch (epi) {
@@ -250,6 +275,36 @@ extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, cons
   return MTAM_OK;
 }
 
+
+extern "C" int mtam_gemm_tn_atomic_grouped(int n, const MtamGemmDesc *d, void *stream) {
+  MTAM_CHECK_ARG(n >= 1 && n <= MTAM_MAX_GROUP && d, "gemm_grouped: 1 <= n <= %d problems", MTAM_MAX_GROUP);
+  GroupArgs ga;
+  ga.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const MtamGemmDesc &q = d[i];
+    MTAM_CHECK_ARG(q.M > 0 && q.N > 0 && q.K > 0 && q.A && q.B && q.C, "gemm_grouped[%d]: bad problem", i);
+    MTAM_CHECK_ARG(q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N, "gemm_grouped[%d]: bad leading dimension", i);
+    int split = q.split_k < 1 ? 1 : q.split_k;
+    int k_chunk = (q.K + split - 1) / split;
+    k_chunk = ((k_chunk + BK - 1) / BK) * BK;
+    split = (q.K + k_chunk - 1) / k_chunk;
+    GemmArgs &a = ga.g[i];
+    a.A = q.A; a.B = q.B; a.C = q.C; a.bias = nullptr; a.aux_in = nullptr; a.aux_out = nullptr;
+    a.M = q.M; a.N = q.N; a.K = q.K; a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.ld_aux = 0;
+    a.k_chunk = k_chunk;
+    a.vecA = (q.lda % 4 == 0) && mtam_aligned16(q.A);
+    a.vecB = (q.ldb % 4 == 0) && mtam_aligned16(q.B);
+    a.tiles_n = (q.N + BN - 1) / BN;
+    ga.first[i] = blocks;
+    blocks += a.tiles_n * ((q.M + BM - 1) / BM) * split;
+  }
+  ga.first[n] = blocks;
+  hipLaunchKernelGGL(gemm_tn_atomic_grouped_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), ga);
+  MTAM_CHECK_LAUNCH("gemm_grouped");
+  return MTAM_OK;
+}
+
 // ---------------------------------------------------------------- column sums
 namespace {
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ in, int rows, int cols,
@@ -278,5 +333,52 @@ extern "C" int mtam_colsum_atomic(const float *in, int rows, int cols, int ld, f
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in, rows, cols,
                      ld, rows_per_block, out);
   MTAM_CHECK_LAUNCH("colsum");
+  return MTAM_OK;
+}
+
+namespace {
+struct ColsumGroup {
+  MtamColsumJob j[MTAM_MAX_GROUP];
+  int first[MTAM_MAX_GROUP + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumGroup cg) {
+  __shared__ float part[4][64];
+  int g = 0;
+  while (g + 1 < cg.n && (int)blockIdx.x >= cg.first[g + 1]) ++g;
+  const MtamColsumJob &q = cg.j[g];
+  const int local = blockIdx.x - cg.first[g];
+  const int col_blocks = (q.cols + 63) / 64;
+  const int c = (local % col_blocks) * 64 + (threadIdx.x & 63);
+  const int rr = threadIdx.x >> 6;
+  const int r0 = (local / col_blocks) * 64;
+  const int r1 = min(q.rows, r0 + 64);
+  float s = 0.f;
+  if (c < q.cols)
+    for (int r = r0 + rr; r < r1; r += 4) s += q.in[(size_t)r * q.ld + c];
+  part[rr][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rr == 0 && c < q.cols) {
+    s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    atomicAdd(q.out + c, s);
+  }
+}
+}  // namespace
+
+extern "C" int mtam_colsum_atomic_multi(int n, const MtamColsumJob *jobs, void *stream) {
+  MTAM_CHECK_ARG(n >= 1 && n <= MTAM_MAX_GROUP && jobs, "colsum_multi: 1 <= n <= %d jobs", MTAM_MAX_GROUP);
+  ColsumGroup cg;
+  cg.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const MtamColsumJob &q = jobs[i];
+    MTAM_CHECK_ARG(q.in && q.out && q.rows > 0 && q.cols > 0 && q.ld >= q.cols, "colsum_multi[%d]: bad job", i);
+    cg.j[i] = q;
+    cg.first[i] = blocks;
+    blocks += ((q.cols + 63) / 64) * ((q.rows + 63) / 64);
+  }
+  cg.first[n] = blocks;
+  hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cg);
+  MTAM_CHECK_LAUNCH("colsum_multi");
   return MTAM_OK;
 }

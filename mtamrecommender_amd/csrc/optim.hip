@@ -31,7 +31,9 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ g
 }
 
 __global__ __launch_bounds__(256) void clip_scale_kernel(const float *__restrict__ partials, int n,
-                                                         float clip, float *__restrict__ scale) {
+                                                         float clip, float *__restrict__ scale,
+                                                         const float *__restrict__ lr,
+                                                         float *__restrict__ adam_state) {
   __shared__ double red[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
@@ -44,20 +46,31 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(const float *__restrict
     // tf.clip_by_global_norm: t * clip_norm * min(1/global_norm, 1/clip_norm)
     scale[0] = clip * fminf(1.0f / norm, 1.0f / clip);
     scale[1] = norm;
+    if (adam_state) {
+      // AdamOptimizer._prepare / _finish [TF1.14]: lr_t from the CURRENT beta powers, then advance them.
+      const float b1 = adam_state[1], b2 = adam_state[2];
+      const float b1p = adam_state[4], b2p = adam_state[5];
+      adam_state[0] = lr[0] * sqrtf(1.0f - b2p) / (1.0f - b1p);
+      adam_state[4] = b1p * b1;
+      adam_state[5] = b2p * b2;
+    }
   }
 }
 
-template <bool SPARSE_FORM>
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m,
                                                    float *__restrict__ v, const float *__restrict__ g, size_t n,
                                                    const float *__restrict__ scale,
-                                                   const float *__restrict__ hyper) {
+                                                   const float *__restrict__ hyper, size_t sparse_begin) {
   const float sc = scale[0];
   const float lr_t = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  const size_t base = (size_t)blockIdx.x * NORM_BLOCK;
+  // elements at or after sparse_begin are table rows (IndexedSlices update form); a block never
+  // straddles the boundary because sparse_begin is a multiple of the block size or 0 / n.
+  const bool sparse_form = base >= sparse_begin;
   auto step = [&](float &pp, float &mm, float &vv, float gg) {
     gg *= sc;
-    if (SPARSE_FORM) {
+    if (sparse_form) {
       mm = mm * b1 + gg * omb1;
       vv = vv * b2 + (gg * gg) * omb2;
     } else {
@@ -66,7 +79,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
     }
     pp = pp - (lr_t * mm) / (sqrtf(vv) + eps);
   };
-  const size_t base = (size_t)blockIdx.x * NORM_BLOCK;
 #pragma unroll
   for (int i = 0; i < NORM_BLOCK / 1024; ++i) {
     const size_t o = base + (size_t)(threadIdx.x + 256 * i) * 4;
@@ -101,23 +113,27 @@ extern "C" int mtam_sqnorm_partial(const float *g, size_t n, float *partial, voi
 }
 
 extern "C" int mtam_clip_scale(const float *partials, int n_partials, float clip_norm, float *scale,
-                               void *stream) {
+                               const float *lr, float *adam_state, void *stream) {
   MTAM_CHECK_ARG(partials && scale && n_partials > 0 && clip_norm > 0.f, "clip_scale: bad arguments");
+  MTAM_CHECK_ARG((lr == nullptr) == (adam_state == nullptr), "clip_scale: lr and adam_state go together");
   hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partials,
-                     n_partials, clip_norm, scale);
+                     n_partials, clip_norm, scale, lr, adam_state);
   MTAM_CHECK_LAUNCH("clip_scale");
   return MTAM_OK;
 }
 
+extern "C" int mtam_adam_block(void) { return NORM_BLOCK; }
+
 extern "C" int mtam_adam(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
-                         const float *hyper, int sparse_form, void *stream) {
+                         const float *hyper, size_t sparse_begin, void *stream) {
   MTAM_CHECK_ARG(p && m && v && g && scale && hyper && n > 0, "adam: bad arguments");
   MTAM_CHECK_ARG(mtam_aligned16(p) && mtam_aligned16(m) && mtam_aligned16(v) && mtam_aligned16(g),
                  "adam: buffers must be 16-byte aligned");
+  MTAM_CHECK_ARG(sparse_begin >= n || sparse_begin % NORM_BLOCK == 0,
+                 "adam: sparse_begin must be a multiple of %d (or >= n)", NORM_BLOCK);
   dim3 grid(mtam_sqnorm_blocks(n));
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (sparse_form) hipLaunchKernelGGL(adam_kernel<true>, grid, dim3(256), 0, s, p, m, v, g, n, scale, hyper);
-  else hipLaunchKernelGGL(adam_kernel<false>, grid, dim3(256), 0, s, p, m, v, g, n, scale, hyper);
+  hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n, scale,
+                     hyper, sparse_begin);
   MTAM_CHECK_LAUNCH("adam");
   return MTAM_OK;
 }

@@ -9,9 +9,10 @@ update, so that replicas stay bit-identical.
 What is exchanged: the dense-parameter gradients AND the
 table gradients -- the item table's gradient is dense because of the
 full-catalog softmax, so replicas diverge if only the attention/GRU parameters
-are reduced.  Two collectives per step:
-  1. the contiguous [dense | category | position | user] gradient arena,
-  2. the item-table gradient [V, D].
+are reduced.  All gradients live in one flat buffer
+[dense | category | position | user | item], so the exchange is ONE all-reduce
+per step (one large collective suits the per-link-bound xGMI ring better than
+many small ones).
 The loss is a mean over the GLOBAL batch (each rank scales by 1/B_global), the
 L2 term is a plain sum, so a sum all-reduce is exact.  The clip norm is the
 true norm of the summed gradient (the TF IndexedSlices norm of App D-5 is a
@@ -44,15 +45,14 @@ def attach(path, world_size, group=None, force=False):
     path.world_size = world_size
 
     def exchange(p, bt):
-        allreduce_gradients([p.zero_arena, p.g_tab["item"]], group)
+        allreduce_gradients([p.flat_g], group)
 
     path.allreduce_fn = exchange
 
 
 def broadcast_parameters(path, src=0, group=None):
     """Replicas start identical (they would anyway with equal seeds; this makes it explicit)."""
-    for t in [path.params] + [path.tables[k] for k in ("user", "item", "category", "position")]:
-        dist.broadcast(t, src=src, group=group)
+    dist.broadcast(path.flat_p, src=src, group=group)
 
 
 def max_over_ranks(value, device):

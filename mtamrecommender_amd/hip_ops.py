@@ -180,13 +180,39 @@ def sqnorm_partial(g, n, partial):
     _lib.check(lib.mtam_sqnorm_partial(_p(g), n, _p(partial), _stream()), "mtam_sqnorm_partial")
 
 
-def clip_scale(partials, n_partials, clip_norm, scale):
+def clip_scale(partials, n_partials, clip_norm, scale, lr=None, adam_state=None):
     lib = _lib.load()
-    _lib.check(lib.mtam_clip_scale(_p(partials), n_partials, float(clip_norm), _p(scale), _stream()),
-               "mtam_clip_scale")
+    _lib.check(lib.mtam_clip_scale(_p(partials), n_partials, float(clip_norm), _p(scale), _p(lr),
+                                   _p(adam_state), _stream()), "mtam_clip_scale")
 
 
-def adam(p, m, v, g, n, scale, hyper, sparse_form):
+def adam_block():
+    return _lib.load().mtam_adam_block()
+
+
+def adam(p, m, v, g, n, scale, hyper, sparse_begin):
     lib = _lib.load()
-    _lib.check(lib.mtam_adam(_p(p), _p(m), _p(v), _p(g), n, _p(scale), _p(hyper), int(sparse_form),
+    _lib.check(lib.mtam_adam(_p(p), _p(m), _p(v), _p(g), n, _p(scale), _p(hyper), int(sparse_begin),
                              _stream()), "mtam_adam")
+
+
+def gemm_tn_atomic_grouped(problems):
+    """problems: list of dicts(A, lda, B, ldb, C, ldc, M, N, K, split_k) with device tensors."""
+    lib = _lib.load()
+    arr = (_lib.GemmDesc * len(problems))()
+    for d, q in zip(arr, problems):
+        d.A, d.B, d.C = _p(q["A"]).value, _p(q["B"]).value, _p(q["C"]).value
+        d.lda, d.ldb, d.ldc = q["lda"], q["ldb"], q["ldc"]
+        d.M, d.N, d.K, d.split_k = q["M"], q["N"], q["K"], q.get("split_k", 1)
+    _lib.check(lib.mtam_gemm_tn_atomic_grouped(len(problems), ctypes.byref(arr), _stream()),
+               "mtam_gemm_tn_atomic_grouped")
+
+
+def colsum_atomic_multi(jobs):
+    """jobs: list of (in_tensor, rows, cols, ld, out_tensor)."""
+    lib = _lib.load()
+    arr = (_lib.ColsumJob * len(jobs))()
+    for d, (x, rows, cols, ld, out) in zip(arr, jobs):
+        d.in_, d.rows, d.cols, d.ld, d.out = _p(x).value, rows, cols, ld, _p(out).value
+    _lib.check(lib.mtam_colsum_atomic_multi(len(jobs), ctypes.byref(arr), _stream()),
+               "mtam_colsum_atomic_multi")

@@ -478,21 +478,55 @@ def test_clip_and_adam(ops):
     assert abs(float(scale[0]) - 1.0 * min(1 / norm, 1.0)) < 1e-7
     ops.clip_scale(part, nb + 2, 1e6, scale)                 # norm below the clip: scale == 1
     assert float(scale[0]) == 1.0
-    ops.clip_scale(part, nb + 2, 1.0, scale)
+    # Adam bookkeeping on the device: lr_t from the current beta powers, then the powers advance
+    state = dev(np.array([0, 0.9, 0.999, 1e-8, 0.9, 0.999, 0, 0], np.float32))
+    lr = dev(np.array([1e-3, 0, 0, 0], np.float32))
+    b1p, b2p = np.float32(0.9), np.float32(0.999)
+    for _ in range(3):
+        ops.clip_scale(part, nb + 2, 1.0, scale, lr, state)
+        st = state.cpu().numpy()
+        want = np.float32(1e-3) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p)
+        assert abs(st[0] - want) <= 1e-6 * want
+        b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+        assert st[4] == b1p and st[5] == b2p
     sc = np.float32(scale[0].item())
     lr_t, b1, b2, eps = np.float32(1e-3), np.float32(0.9), np.float32(0.999), np.float32(1e-8)
     hyper = dev(np.array([lr_t, b1, b2, eps], np.float32))
-    for sparse in (0, 1):
+    blk = ops.adam_block()
+    for sparse_begin in (n, 0, blk):
         p, m, v = dev(p0).clone(), dev(m0).clone(), dev(v0).clone()
-        ops.adam(p, m, v, dev(g), n, scale, hyper, sparse)
+        ops.adam(p, m, v, dev(g), n, scale, hyper, sparse_begin)
         gs = g * sc
-        if sparse:
-            mr = m0 * b1 + gs * (np.float32(1) - b1)
-            vr = v0 * b2 + (gs * gs) * (np.float32(1) - b2)
-        else:
-            mr = m0 + (gs - m0) * (np.float32(1) - b1)
-            vr = v0 + (gs * gs - v0) * (np.float32(1) - b2)
+        sparse = np.arange(n) >= sparse_begin
+        mr = np.where(sparse, m0 * b1 + gs * (np.float32(1) - b1), m0 + (gs - m0) * (np.float32(1) - b1))
+        vr = np.where(sparse, v0 * b2 + (gs * gs) * (np.float32(1) - b2), v0 + (gs * gs - v0) * (np.float32(1) - b2))
         pr = p0 - (lr_t * mr) / (np.sqrt(vr) + eps)
         assert np.allclose(m.cpu().numpy(), mr, rtol=1e-6, atol=1e-9)
         assert np.allclose(v.cpu().numpy(), vr, rtol=1e-6, atol=1e-9)
         assert np.allclose(p.cpu().numpy(), pr, rtol=1e-6, atol=1e-7)
+
+
+def test_grouped_weight_gradient_gemm_and_colsum(ops):
+    rng = np.random.default_rng(8)
+    shapes = [(1850, 128, 384, 7), (1850, 256, 128, 3), (37, 128, 256, 1), (700, 128, 128, 16)]   # K, M, N, split
+    probs, refs, outs = [], [], []
+    for K, M, N, split in shapes:
+        A = rng.standard_normal((K, M + 5)).astype(np.float32)         # lda > M
+        Bm = rng.standard_normal((K, N)).astype(np.float32)
+        c0 = rng.standard_normal((M, N)).astype(np.float32)
+        C = dev(c0).clone()
+        probs.append(dict(A=dev(A), lda=M + 5, B=dev(Bm), ldb=N, C=C, ldc=N, M=M, N=N, K=K, split_k=split))
+        refs.append(c0 + A[:, :M].T.astype(np.float64) @ Bm.astype(np.float64))
+        outs.append(C)
+    ops.gemm_tn_atomic_grouped(probs)
+    for C, ref in zip(outs, refs):
+        assert rel_err(C.cpu().numpy(), ref) < 5e-6
+    jobs, wants = [], []
+    for rows, cols, ld in [(777, 300, 300), (128, 128, 256), (5, 70, 70)]:
+        x = rng.standard_normal((rows, ld)).astype(np.float32)
+        out = torch.ones(cols, device="cuda")
+        jobs.append((dev(x), rows, cols, ld, out))
+        wants.append(1.0 + x[:, :cols].astype(np.float64).sum(0))
+    ops.colsum_atomic_multi(jobs)
+    for (_, _, _, _, out), want in zip(jobs, wants):
+        assert rel_err(out.cpu().numpy(), want) < 1e-5
