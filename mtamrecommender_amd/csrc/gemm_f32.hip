@@ -8,8 +8,9 @@
 // result of one output element does not depend on the tile it falls in.
 // Operands are staged global -> registers -> LDS in k-major order
 // (As[k][m], Bs[k][n]) so that the MFMA fragment reads (lane = m or n) are
-// bank-conflict free; the next k-tile's global loads are in flight while the
-// current one is multiplied.
+// bank-conflict free.  LDS is double buffered: while k-tile kt is multiplied,
+// tile kt+1 moves registers -> LDS and tile kt+2's global loads are issued
+// (straight-line 16-B loads on the wave-uniform fast path), one barrier per tile.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,27 +33,30 @@ struct GemmArgs {
 };
 
 // Source laid out src[r][k] (k contiguous): tile of 64 rows x 32 k.
+// FAST: the whole tile is in range and 16-B aligned (decided per block / per k-tile, wave-uniform),
+// so the loads are straight-line dwordx4 with nothing between them for the compiler to wait on.
+template <bool FAST>
 __device__ __forceinline__ void load_kcontig(const float *__restrict__ src, int ld, int rows, int r0,
-                                             int k0, int kend, bool vec, float4 (&reg)[2]) {
+                                             int k0, int kend, float4 (&reg)[2]) {
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = t + 256 * i;
     const int r = r0 + (idx >> 3);
     const int k = k0 + 4 * (idx & 7);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rows) {
-      const float *p = src + (size_t)r * ld + k;
-      if (vec && k + 3 < kend) {
-        v = *reinterpret_cast<const float4 *>(p);
-      } else {
+    if (FAST) {
+      reg[i] = *reinterpret_cast<const float4 *>(src + (size_t)r * ld + k);
+    } else {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < rows) {
+        const float *p = src + (size_t)r * ld + k;
         if (k + 0 < kend) v.x = p[0];
         if (k + 1 < kend) v.y = p[1];
         if (k + 2 < kend) v.z = p[2];
         if (k + 3 < kend) v.w = p[3];
       }
+      reg[i] = v;
     }
-    reg[i] = v;
   }
 }
 __device__ __forceinline__ void store_kcontig(float *__restrict__ S, const float4 (&reg)[2]) {
@@ -70,27 +74,28 @@ __device__ __forceinline__ void store_kcontig(float *__restrict__ S, const float
 }
 
 // Source laid out src[k][c] (c contiguous): tile of 32 k x 64 columns.
+template <bool FAST>
 __device__ __forceinline__ void load_ccontig(const float *__restrict__ src, int ld, int cols, int c0,
-                                             int k0, int kend, bool vec, float4 (&reg)[2]) {
+                                             int k0, int kend, float4 (&reg)[2]) {
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = t + 256 * i;
     const int k = k0 + (idx >> 4);
     const int c = c0 + 4 * (idx & 15);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < kend) {
-      const float *p = src + (size_t)k * ld + c;
-      if (vec && c + 3 < cols) {
-        v = *reinterpret_cast<const float4 *>(p);
-      } else {
+    if (FAST) {
+      reg[i] = *reinterpret_cast<const float4 *>(src + (size_t)k * ld + c);
+    } else {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < kend) {
+        const float *p = src + (size_t)k * ld + c;
         if (c + 0 < cols) v.x = p[0];
         if (c + 1 < cols) v.y = p[1];
         if (c + 2 < cols) v.z = p[2];
         if (c + 3 < cols) v.w = p[3];
       }
+      reg[i] = v;
     }
-    reg[i] = v;
   }
 }
 __device__ __forceinline__ void store_ccontig(float *__restrict__ S, const float4 (&reg)[2]) {
@@ -104,6 +109,10 @@ __device__ __forceinline__ void store_ccontig(float *__restrict__ S, const float
   }
 }
 
+constexpr int TILE_FLOATS = BK * LDM;   // one operand tile in LDS
+
+// One 64x64 output tile over one K slice.  LDS: As[2][TILE_FLOATS], Bs[2][TILE_FLOATS]
+// (double buffered: the tile for step kt+1 is written while step kt is multiplied; one barrier per step).
 template <bool TA, bool TB, int EPI>
 __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *Bs, int tile, int kslice) {
   constexpr int LDA_S = TA ? LDM : LDK;
@@ -115,6 +124,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
   const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
   const int kbeg = kslice * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
+  // wave-uniform: whole tile rows/columns in range and vector loads legal
+  const bool fullA = p.vecA && (m0 + BM <= p.M);
+  const bool fullB = p.vecB && (n0 + BN <= p.N);
 
   f32x16 acc;
 #pragma unroll
@@ -122,36 +134,52 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
 
   float4 ra[2], rb[2];
   auto load_tiles = [&](int k0) {
-    if (TA) load_ccontig(p.A, p.lda, p.M, m0, k0, kend, p.vecA, ra);
-    else    load_kcontig(p.A, p.lda, p.M, m0, k0, kend, p.vecA, ra);
-    if (TB) load_kcontig(p.B, p.ldb, p.N, n0, k0, kend, p.vecB, rb);
-    else    load_ccontig(p.B, p.ldb, p.N, n0, k0, kend, p.vecB, rb);
+    const bool fullK = (k0 + BK <= kend);
+    if (fullA && fullK) {
+      if (TA) load_ccontig<true>(p.A, p.lda, p.M, m0, k0, kend, ra);
+      else    load_kcontig<true>(p.A, p.lda, p.M, m0, k0, kend, ra);
+    } else {
+      if (TA) load_ccontig<false>(p.A, p.lda, p.M, m0, k0, kend, ra);
+      else    load_kcontig<false>(p.A, p.lda, p.M, m0, k0, kend, ra);
+    }
+    if (fullB && fullK) {
+      if (TB) load_kcontig<true>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+      else    load_ccontig<true>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+    } else {
+      if (TB) load_kcontig<false>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+      else    load_ccontig<false>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+    }
   };
-  auto store_tiles = [&]() {
-    if (TA) store_ccontig(As, ra); else store_kcontig(As, ra);
-    if (TB) store_kcontig(Bs, rb); else store_ccontig(Bs, rb);
+  auto store_tiles = [&](int buf) {
+    float *a = As + buf * TILE_FLOATS, *b = Bs + buf * TILE_FLOATS;
+    if (TA) store_ccontig(a, ra); else store_kcontig(a, ra);
+    if (TB) store_kcontig(b, rb); else store_ccontig(b, rb);
   };
 
   if (kbeg < kend) {
+    const int nk = (kend - kbeg + BK - 1) / BK;
     load_tiles(kbeg);
-    store_tiles();
+    store_tiles(0);
+    if (nk > 1) load_tiles(kbeg + BK);
     __syncthreads();
     const int a_off = (lane >> 5) * LDA_S + wm * 32 + (lane & 31);
     const int b_off = (lane >> 5) * LDB_S + wn * 32 + (lane & 31);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      const bool more = (k0 + BK) < kend;
-      if (more) load_tiles(k0 + BK);
+    for (int kt = 0; kt < nk; ++kt) {
+      const float *a_s = As + (kt & 1) * TILE_FLOATS + a_off;
+      const float *b_s = Bs + (kt & 1) * TILE_FLOATS + b_off;
+      float fa[BK / 2], fb[BK / 2];
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        const float a = As[kk * LDA_S + a_off];
-        const float b = Bs[kk * LDB_S + b_off];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      for (int q = 0; q < BK / 2; ++q) {
+        fa[q] = a_s[2 * q * LDA_S];
+        fb[q] = b_s[2 * q * LDB_S];
+      }
+#pragma unroll
+      for (int q = 0; q < BK / 2; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
+      if (kt + 1 < nk) {
+        store_tiles((kt + 1) & 1);                       // registers hold tile kt+1 (loaded one step ago)
+        if (kt + 2 < nk) load_tiles(kbeg + (kt + 2) * BK);
       }
       __syncthreads();
-      if (more) {
-        store_tiles();
-        __syncthreads();
-      }
     }
   }
 
@@ -192,8 +220,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
 
 template <bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float As[BK * LDM];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDM];
+  __shared__ __attribute__((aligned(16))) float As[2 * TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * TILE_FLOATS];
   // 1-D tile index (grid.y is capped at 65535; V/64 is not), split-K slice on grid.y
   gemm_tile<TA, TB, EPI>(p, As, Bs, blockIdx.x, blockIdx.y);
 }
@@ -208,8 +236,8 @@ struct GroupArgs {
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_atomic_grouped_kernel(GroupArgs ga) {
-  __shared__ __attribute__((aligned(16))) float As[BK * LDM];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDM];
+  __shared__ __attribute__((aligned(16))) float As[2 * TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * TILE_FLOATS];
   int g = 0;
   while (g + 1 < ga.n && (int)blockIdx.x >= ga.first[g + 1]) ++g;
   const GemmArgs &p = ga.g[g];
