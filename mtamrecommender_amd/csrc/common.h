@@ -46,3 +46,23 @@ __device__ __forceinline__ float group_sum(float v, int width) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Hardware-transcendental forms for the serial GRU / attention steps, where the accurate libm
+// sequences (about 25 instructions for a sigmoid, 35 for a tanh) sit on the critical path.
+// v_exp_f32 and v_rcp_f32 are 1-ulp instructions; the results below stay within a few ulp
+// (relative) of the libm values, which the parity tolerances (>= 2e-5) absorb.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return fast_exp2(1.4426950408889634f * x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp2(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float ax = fabsf(x), x2 = x * x;
+  // |x| < 0.3: odd Taylor polynomial (truncation < 2e-8 relative); else (1 - e^-2|x|) / (1 + e^-2|x|)
+  const float p = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 0.021869488f, -0.053968254f), 0.13333334f), -0.33333334f), 1.0f);
+  const float t = fast_exp2(-2.8853900817779268f * ax);
+  const float r = copysignf((1.0f - t) * fast_rcp(1.0f + t), x);
+  return ax < 0.3f ? p : r;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }

@@ -55,48 +55,71 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
   if (tid < D) q_s[tid] = p.dec_in[(size_t)b * D + tid];
   __syncthreads();
 
-  // [Q | qt] = q . [Wq | Wt]; thread = output column, coalesced weight reads
+  // [Q | qt] = q . [Wq | Wt]; thread = output column, coalesced weight reads, 16 loads in flight
   {
     float acc = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < D; k += 4) {
-      const float4 qv = *reinterpret_cast<const float4 *>(&q_s[k]);
-      acc = fmaf(qv.x, p.wqt[(size_t)(k + 0) * (2 * D) + tid], acc);
-      acc = fmaf(qv.y, p.wqt[(size_t)(k + 1) * (2 * D) + tid], acc);
-      acc = fmaf(qv.z, p.wqt[(size_t)(k + 2) * (2 * D) + tid], acc);
-      acc = fmaf(qv.w, p.wqt[(size_t)(k + 3) * (2 * D) + tid], acc);
+    for (int k0 = 0; k0 < D; k0 += 16) {
+      float wv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wv[i] = p.wqt[(size_t)(k0 + i) * (2 * D) + tid];
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+        const float4 qv = *reinterpret_cast<const float4 *>(&q_s[k0 + i]);
+        acc = fmaf(qv.x, wv[i], acc);
+        acc = fmaf(qv.y, wv[i + 1], acc);
+        acc = fmaf(qv.z, wv[i + 2], acc);
+        acc = fmaf(qv.w, wv[i + 3], acc);
+      }
     }
     if (tid < D) Q_s[tid] = fmaxf(acc + p.bq[tid], 0.f);
     else qt_s[tid - D] = acc;
   }
   __syncthreads();
 
-  // scores: half a wave per key row
+  // scores: half a wave per key row; the rows of up to KB keys per half wave are loaded before any
+  // of them is reduced, so the key loop is not a chain of exposed global-load latencies
   {
     const int hw = tid >> 5, li = tid & 31;
     const float4 Q4 = *reinterpret_cast<const float4 *>(&Q_s[4 * li]);
     const float4 T4 = *reinterpret_cast<const float4 *>(&qt_s[4 * li]);
     const float tq = p.t_query[b];
-    for (int j = hw; j < L; j += 8) {
-      if (j < sl) {
-        const float4 kq = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.k_off + 4 * li]);
-        const float4 xq = *reinterpret_cast<const float4 *>(&p.x[(row0 + j) * D + 4 * li]);
-        const float dK = group_sum(dot4(kq, Q4), lanes_per_head);
-        const float dA = group_sum(dot4(xq, T4), 32);
-        const float a = tanhf(dA);
-        const float delta = logf(fabsf(tq - p.t_keys[row0 + j]) + 1.0f);
-        const float dk = tanhf(delta * p.tparams[j] + p.tparams[L + j]);
-        const float g = p.tparams[2 * L + j] * dk + p.tparams[3 * L + j] * a + p.tparams[4 * L + j];
-        const float sg = sigmoidf_(g);
-        if ((li % lanes_per_head) == 0) {
-          const int h = li / lanes_per_head;
-          qk_s[h][j] = dK;
-          sc_s[h][j] = (dK * sg) / inv_div;
+    constexpr int KB = 8;
+    for (int jb = hw; jb < L; jb += 8 * KB) {
+      float4 kq[KB], xq[KB];
+      float tk[KB], tp[KB][5];
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        const int j = jb + 8 * i;
+        if (j < sl) {
+          kq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.k_off + 4 * li]);
+          xq[i] = *reinterpret_cast<const float4 *>(&p.x[(row0 + j) * D + 4 * li]);
+          tk[i] = p.t_keys[row0 + j];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) tp[i][q] = p.tparams[q * L + j];
         }
-        if (li == 0) { a_s[j] = a; dk_s[j] = dk; sg_s[j] = sg; }
-      } else {
-        if (li < H) { qk_s[li][j] = 0.f; sc_s[li][j] = MASK_VALUE; }
-        if (li == 0) { a_s[j] = 0.f; dk_s[j] = 0.f; sg_s[j] = 0.f; }
+      }
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        const int j = jb + 8 * i;
+        if (j >= L) break;
+        if (j < sl) {
+          const float dK = group_sum(dot4(kq[i], Q4), lanes_per_head);
+          const float dA = group_sum(dot4(xq[i], T4), 32);
+          const float a = fast_tanh(dA);
+          const float delta = logf(fabsf(tq - tk[i]) + 1.0f);
+          const float dk = fast_tanh(delta * tp[i][0] + tp[i][1]);
+          const float g = tp[i][2] * dk + tp[i][3] * a + tp[i][4];
+          const float sg = fast_sigmoid(g);
+          if ((li % lanes_per_head) == 0) {
+            const int h = li / lanes_per_head;
+            qk_s[h][j] = dK;
+            sc_s[h][j] = (dK * sg) / inv_div;
+          }
+          if (li == 0) { a_s[j] = a; dk_s[j] = dk; sg_s[j] = sg; }
+        } else {
+          if (li < H) { qk_s[li][j] = 0.f; sc_s[li][j] = MASK_VALUE; }
+          if (li == 0) { a_s[j] = 0.f; dk_s[j] = 0.f; sg_s[j] = 0.f; }
+        }
       }
     }
   }
@@ -109,7 +132,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
     m = wave_max(m);
     float s = 0.f;
     for (int j = lane; j < L; j += 64) {
-      const float e = expf(sc_s[h][j] - m);
+      const float e = fast_exp(sc_s[h][j] - m);
       sc_s[h][j] = e;
       s += e;
     }
@@ -118,14 +141,21 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
   }
   __syncthreads();
 
-  // O = W . V  (thread = channel, keys split in two halves)
+  // O = W . V  (thread = channel, keys split in two halves, 8 value rows in flight)
   {
     const int c = tid & (D - 1), part = tid >> 7;
     const int h = c / (D / H);
     const int jmid = (sl + 1) / 2;
     const int j0 = part ? jmid : 0, j1 = part ? sl : jmid;
     float o = 0.f;
-    for (int j = j0; j < j1; ++j) o = fmaf(sc_s[h][j], p.kv[(row0 + j) * p.ld_kv + p.v_off + c], o);
+    for (int jb = j0; jb < j1; jb += 8) {
+      float vv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vv[i] = (jb + i < j1) ? p.kv[(row0 + jb + i) * p.ld_kv + p.v_off + c] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (jb + i < j1) o = fmaf(sc_s[h][jb + i], vv[i], o);
+    }
     o_part[part][c] = o;
   }
   __syncthreads();
@@ -235,16 +265,27 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
 
   const int hw = tid >> 5, li = tid & 31;
   const int head_of_lane = li / lanes_per_head;
-  // ---- dW[h][j] = dO_h . V_j
+  // ---- dW[h][j] = dO_h . V_j   (value rows of KB keys per half wave loaded before reducing)
+  constexpr int KB = 8;
   {
     const float4 dO4 = *reinterpret_cast<const float4 *>(&dO_s[4 * li]);
-    for (int j = hw; j < L; j += 8) {
-      if (j < sl) {
-        const float4 vq = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.v_off + 4 * li]);
-        const float dW = group_sum(dot4(vq, dO4), lanes_per_head);
-        if ((li % lanes_per_head) == 0) ds_s[head_of_lane][j] = dW;
-      } else if (li < H) {
-        ds_s[li][j] = 0.f;
+    for (int jb = hw; jb < L; jb += 8 * KB) {
+      float4 vq[KB];
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        const int j = jb + 8 * i;
+        if (j < sl) vq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.v_off + 4 * li]);
+      }
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        const int j = jb + 8 * i;
+        if (j >= L) break;
+        if (j < sl) {
+          const float dW = group_sum(dot4(vq[i], dO4), lanes_per_head);
+          if ((li % lanes_per_head) == 0) ds_s[head_of_lane][j] = dW;
+        } else if (li < H) {
+          ds_s[li][j] = 0.f;
+        }
       }
     }
   }
@@ -291,36 +332,46 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     const float4 T4 = *reinterpret_cast<const float4 *>(&qt_s[4 * li]);
     float4 aQ = make_float4(0.f, 0.f, 0.f, 0.f), aT = aQ;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = hw; j < L; j += 8) {
-      float *dk_row = p.d_kv + (row0 + j) * p.ld_kv + p.k_off + 4 * li;
-      float *dv_row = p.d_kv + (row0 + j) * p.ld_kv + p.v_off + 4 * li;
-      float *dx_row = p.d_x + (row0 + j) * D + 4 * li;
-      if (j < sl) {
-        const float4 kq = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.k_off + 4 * li]);
-        const float4 vq = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.v_off + 4 * li]);
-        const float4 xq = *reinterpret_cast<const float4 *>(&p.x[(row0 + j) * D + 4 * li]);
-        const float wj = w_s[head_of_lane][j], dqk = ds_s[head_of_lane][j], dap = dap_s[j];
-        float4 dv, dk;
-        dv.x = vq.x > 0.f ? wj * dO4.x : 0.f; dv.y = vq.y > 0.f ? wj * dO4.y : 0.f;
-        dv.z = vq.z > 0.f ? wj * dO4.z : 0.f; dv.w = vq.w > 0.f ? wj * dO4.w : 0.f;
-        dk.x = kq.x > 0.f ? dqk * Q4.x : 0.f; dk.y = kq.y > 0.f ? dqk * Q4.y : 0.f;
-        dk.z = kq.z > 0.f ? dqk * Q4.z : 0.f; dk.w = kq.w > 0.f ? dqk * Q4.w : 0.f;
-        *reinterpret_cast<float4 *>(dv_row) = dv;
-        *reinterpret_cast<float4 *>(dk_row) = dk;
-        float4 dx = make_float4(dap * T4.x, dap * T4.y, dap * T4.z, dap * T4.w);
-        if (p.accumulate_dx) {
-          const float4 o = *reinterpret_cast<const float4 *>(dx_row);
-          dx.x += o.x; dx.y += o.y; dx.z += o.z; dx.w += o.w;
+    for (int jb = hw; jb < L; jb += 8 * KB) {
+      float4 kq[KB], vq[KB], xq[KB], ox[KB];
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        const int j = jb + 8 * i;
+        if (j < sl) {
+          kq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.k_off + 4 * li]);
+          vq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.v_off + 4 * li]);
+          xq[i] = *reinterpret_cast<const float4 *>(&p.x[(row0 + j) * D + 4 * li]);
+          if (p.accumulate_dx) ox[i] = *reinterpret_cast<const float4 *>(&p.d_x[(row0 + j) * D + 4 * li]);
         }
-        *reinterpret_cast<float4 *>(dx_row) = dx;
-        aQ.x = fmaf(dqk, kq.x, aQ.x); aQ.y = fmaf(dqk, kq.y, aQ.y);
-        aQ.z = fmaf(dqk, kq.z, aQ.z); aQ.w = fmaf(dqk, kq.w, aQ.w);
-        aT.x = fmaf(dap, xq.x, aT.x); aT.y = fmaf(dap, xq.y, aT.y);
-        aT.z = fmaf(dap, xq.z, aT.z); aT.w = fmaf(dap, xq.w, aT.w);
-      } else {
-        *reinterpret_cast<float4 *>(dv_row) = zero4;
-        *reinterpret_cast<float4 *>(dk_row) = zero4;
-        if (!p.accumulate_dx) *reinterpret_cast<float4 *>(dx_row) = zero4;
+      }
+#pragma unroll
+      for (int i = 0; i < KB; ++i) {
+        const int j = jb + 8 * i;
+        if (j >= L) break;
+        float *dk_row = p.d_kv + (row0 + j) * p.ld_kv + p.k_off + 4 * li;
+        float *dv_row = p.d_kv + (row0 + j) * p.ld_kv + p.v_off + 4 * li;
+        float *dx_row = p.d_x + (row0 + j) * D + 4 * li;
+        if (j < sl) {
+          const float wj = w_s[head_of_lane][j], dqk = ds_s[head_of_lane][j], dap = dap_s[j];
+          float4 dv, dk;
+          dv.x = vq[i].x > 0.f ? wj * dO4.x : 0.f; dv.y = vq[i].y > 0.f ? wj * dO4.y : 0.f;
+          dv.z = vq[i].z > 0.f ? wj * dO4.z : 0.f; dv.w = vq[i].w > 0.f ? wj * dO4.w : 0.f;
+          dk.x = kq[i].x > 0.f ? dqk * Q4.x : 0.f; dk.y = kq[i].y > 0.f ? dqk * Q4.y : 0.f;
+          dk.z = kq[i].z > 0.f ? dqk * Q4.z : 0.f; dk.w = kq[i].w > 0.f ? dqk * Q4.w : 0.f;
+          *reinterpret_cast<float4 *>(dv_row) = dv;
+          *reinterpret_cast<float4 *>(dk_row) = dk;
+          float4 dx = make_float4(dap * T4.x, dap * T4.y, dap * T4.z, dap * T4.w);
+          if (p.accumulate_dx) { dx.x += ox[i].x; dx.y += ox[i].y; dx.z += ox[i].z; dx.w += ox[i].w; }
+          *reinterpret_cast<float4 *>(dx_row) = dx;
+          aQ.x = fmaf(dqk, kq[i].x, aQ.x); aQ.y = fmaf(dqk, kq[i].y, aQ.y);
+          aQ.z = fmaf(dqk, kq[i].z, aQ.z); aQ.w = fmaf(dqk, kq[i].w, aQ.w);
+          aT.x = fmaf(dap, xq[i].x, aT.x); aT.y = fmaf(dap, xq[i].y, aT.y);
+          aT.z = fmaf(dap, xq[i].z, aT.z); aT.w = fmaf(dap, xq[i].w, aT.w);
+        } else {
+          *reinterpret_cast<float4 *>(dv_row) = zero4;
+          *reinterpret_cast<float4 *>(dk_row) = zero4;
+          if (!p.accumulate_dx) *reinterpret_cast<float4 *>(dx_row) = zero4;
+        }
       }
     }
     *reinterpret_cast<float4 *>(&partQ[hw][4 * li]) = aQ;
@@ -343,12 +394,21 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     float dq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[i] = dqp_s[lane + 64 * i];
-    for (int c = w; c < D; c += 4) {
-      float s = 0.f;
+    for (int c0 = w; c0 < D; c0 += 4 * 8) {          // 8 rows (32 loads) in flight per wave
+      float wv[8][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s = fmaf(dq[i], p.wqt[(size_t)c * (2 * D) + lane + 64 * i], s);
-      s = wave_sum(s);
-      if (lane == 0) p.d_dec_in[(size_t)b * D + c] = s + dO_s[c];
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[r][i] = p.wqt[(size_t)(c0 + 4 * r) * (2 * D) + lane + 64 * i];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s = fmaf(dq[i], wv[r][i], s);
+        s = wave_sum(s);
+        const int c = c0 + 4 * r;
+        if (lane == 0) p.d_dec_in[(size_t)b * D + c] = s + dO_s[c];
+      }
     }
   }
 }

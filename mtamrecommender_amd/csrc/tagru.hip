@@ -35,6 +35,7 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
   __shared__ __attribute__((aligned(16))) float h_s[D];
   __shared__ __attribute__((aligned(16))) float rh_s[D];
   __shared__ float u_s[D];
+  __shared__ float T_s[D];
   __shared__ float pg[NW][2 * D];
   __shared__ float pc[NW][D];
 
@@ -43,40 +44,48 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
   const int steps = min(max(p.seq_len[b] - 1, 0), p.L);
   const size_t row0 = (size_t)b * p.L;
 
-  // recurrent weights -> registers (coalesced: lanes run along the output column)
-  float wg[16][4], wc[16][2];
+  // recurrent weights -> registers (coalesced: lanes run along the output column), packed in pairs
+  // of columns so that the inner products issue as v_pk_fma_f32
+  f32x2 wg[16][2], wc[16];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wg[kk][j] = p.wh_g[(size_t)(16 * w + kk) * (2 * D) + lane + 64 * j];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) wc[kk][j] = p.wh_c[(size_t)(16 * w + kk) * D + lane + 64 * j];
+    const float *rg = p.wh_g + (size_t)(16 * w + kk) * (2 * D) + lane;
+    const float *rc = p.wh_c + (size_t)(16 * w + kk) * D + lane;
+    wg[kk][0] = f32x2{rg[0], rg[64]};
+    wg[kk][1] = f32x2{rg[128], rg[192]};
+    wc[kk] = f32x2{rc[0], rc[64]};
   }
+  // Roles of the finalize phases (one column per thread):
+  //   threads   0..127  r gate (critical path), then the candidate / new state
+  //   threads 128..255  u gate
+  //   threads 256..383  time gate T (needs only x_t, dt and the OLD state: off the critical path)
+  const int col = tid & (D - 1);
+  const bool is_T = (tid >= 2 * D) && (tid < 3 * D);
   float tv[NTV];
 #pragma unroll
-  for (int i = 0; i < NTV; ++i) tv[i] = (tid < D) ? p.tvec[i * D + tid] : 0.f;
+  for (int i = 0; i < NTV; ++i) tv[i] = (is_T) ? p.tvec[i * D + col] : 0.f;
 
   if (tid < D) h_s[tid] = 0.f;
 
   // software prefetch of step t's inputs (independent of the recurrence)
-  float n_xg = 0.f, n_xc = 0.f, n_x = 0.f, n_dl = 0.f;
+  float n_a = 0.f, n_b = 0.f;
   auto prefetch = [&](int t) {
     const size_t r = row0 + t;
-    if (tid < 2 * D) n_xg = p.xproj[r * (3 * D) + tid];
-    if (tid < D) {
-      n_xc = p.xproj[r * (3 * D) + 2 * D + tid];
-      n_x = p.x[r * D + tid];
-      n_dl = p.timelast[r];
+    if (tid < 2 * D) n_a = p.xproj[r * (3 * D) + tid];             // gate pre-activation, input half
+    if (tid < D) n_b = p.xproj[r * (3 * D) + 2 * D + tid];         // candidate pre-activation, input half
+    if (is_T) {
+      n_a = p.x[r * D + col];
+      n_b = p.timelast[r];
     }
   };
   if (steps > 0) prefetch(0);
   __syncthreads();
 
   for (int t = 0; t < steps; ++t) {
-    const float xg = n_xg, xc = n_xc, xt = n_x, dl = n_dl;
+    const float in_a = n_a, in_b = n_b;
     if (t + 1 < steps) prefetch(t + 1);
 
-    // phase 1: gate pre-activations, recurrent half
+    // phase 1: gate pre-activations, recurrent half (all waves: k slice 16w..16w+15, 4 columns per lane)
     {
       float hv[16];
 #pragma unroll
@@ -84,30 +93,36 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
         const float4 v = *reinterpret_cast<const float4 *>(&h_s[16 * w + 4 * q]);
         hv[4 * q] = v.x; hv[4 * q + 1] = v.y; hv[4 * q + 2] = v.z; hv[4 * q + 3] = v.w;
       }
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(hv[kk], wg[kk][j], acc[j]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pg[w][lane + 64 * j] = acc[j];
+      for (int kk = 0; kk < 16; ++kk) {
+        const f32x2 h2 = {hv[kk], hv[kk]};
+        a0 = pk_fma(h2, wg[kk][0], a0);
+        a1 = pk_fma(h2, wg[kk][1], a1);
+      }
+      pg[w][lane] = a0.x; pg[w][lane + 64] = a0.y; pg[w][lane + 128] = a1.x; pg[w][lane + 192] = a1.y;
     }
     __syncthreads();
     float r_keep = 0.f;
     if (tid < 2 * D) {
-      float g = xg;
+      float g = in_a;
 #pragma unroll
       for (int q = 0; q < NW; ++q) g += pg[q][tid];
-      const float s = sigmoidf_(g);
+      const float s = fast_sigmoid(g);
       if (tid < D) {
         r_keep = s;
         rh_s[tid] = s * h_s[tid];
       } else {
         u_s[tid - D] = s;
       }
+    } else if (is_T) {
+      const float h = h_s[col];
+      const float tw = fmaxf(in_a * tv[KW1] + tv[KB1] + h * tv[HW1], 0.f);
+      const float ts = fmaxf(tv[W1] * in_b + tv[B1], 0.f);
+      T_s[col] = fast_sigmoid(tv[KW2] * tw + tv[W12] * ts + tv[B12]);
     }
     __syncthreads();
-    // phase 2: candidate pre-activation, recurrent half on r*h
+    // phase 2: candidate pre-activation, recurrent half on r*h (2 columns per lane)
     {
       float rv[16];
 #pragma unroll
@@ -115,33 +130,26 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
         const float4 v = *reinterpret_cast<const float4 *>(&rh_s[16 * w + 4 * q]);
         rv[4 * q] = v.x; rv[4 * q + 1] = v.y; rv[4 * q + 2] = v.z; rv[4 * q + 3] = v.w;
       }
-      float acc[2] = {0.f, 0.f};
+      f32x2 a = {0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = fmaf(rv[kk], wc[kk][j], acc[j]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) pc[w][lane + 64 * j] = acc[j];
+      for (int kk = 0; kk < 16; ++kk) a = pk_fma(f32x2{rv[kk], rv[kk]}, wc[kk], a);
+      pc[w][lane] = a.x; pc[w][lane + 64] = a.y;
     }
     __syncthreads();
     if (tid < D) {
-      float cp = xc;
+      float cp = in_b;
 #pragma unroll
       for (int q = 0; q < NW; ++q) cp += pc[q][tid];
-      const float c = tanhf(cp);
-      const float h = h_s[tid];
-      const float tw = fmaxf(xt * tv[KW1] + tv[KB1] + h * tv[HW1], 0.f);
-      const float ts = fmaxf(tv[W1] * dl + tv[B1], 0.f);
-      const float T = sigmoidf_(tv[KW2] * tw + tv[W12] * ts + tv[B12]);
-      const float u = u_s[tid];
+      const float c = fast_tanh(cp);
+      const float h = h_s[tid], u = u_s[tid], T = T_s[tid];
       const float hn = u * h + (1.f - u) * c * T;
+      h_s[tid] = hn;
       const size_t r = row0 + t;
       p.hs[r * D + tid] = hn;
       if (p.save) {
         float *sv = p.save + r * (5 * D) + tid;
         sv[0] = r_keep; sv[D] = u; sv[2 * D] = c; sv[3 * D] = T; sv[4 * D] = h;
       }
-      h_s[tid] = hn;
     }
     __syncthreads();
   }
@@ -173,20 +181,21 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
 
   // transposed recurrent weights -> registers: lane owns outputs k = lane, lane + 64;
   // wave w owns n in [16w,16w+16) of the candidate kernel and [32w,32w+32) of the gate kernel.
-  float wcT[16][2], wgT[32][2];
+  // (pairs {k = lane, k = lane + 64} packed for v_pk_fma_f32)
+  f32x2 wcT[16], wgT[32];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int k = lane + 64 * j;
+  for (int q = 0; q < 4; ++q) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(&p.wh_c[(size_t)lane * D + 16 * w + 4 * q]);
+    const float4 v1 = *reinterpret_cast<const float4 *>(&p.wh_c[(size_t)(lane + 64) * D + 16 * w + 4 * q]);
+    wcT[4 * q] = f32x2{v0.x, v1.x}; wcT[4 * q + 1] = f32x2{v0.y, v1.y};
+    wcT[4 * q + 2] = f32x2{v0.z, v1.z}; wcT[4 * q + 3] = f32x2{v0.w, v1.w};
+  }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4 *>(&p.wh_c[(size_t)k * D + 16 * w + 4 * q]);
-      wcT[4 * q][j] = v.x; wcT[4 * q + 1][j] = v.y; wcT[4 * q + 2][j] = v.z; wcT[4 * q + 3][j] = v.w;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 v = *reinterpret_cast<const float4 *>(&p.wh_g[(size_t)k * (2 * D) + 32 * w + 4 * q]);
-      wgT[4 * q][j] = v.x; wgT[4 * q + 1][j] = v.y; wgT[4 * q + 2][j] = v.z; wgT[4 * q + 3][j] = v.w;
-    }
+  for (int q = 0; q < 8; ++q) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(&p.wh_g[(size_t)lane * (2 * D) + 32 * w + 4 * q]);
+    const float4 v1 = *reinterpret_cast<const float4 *>(&p.wh_g[(size_t)(lane + 64) * (2 * D) + 32 * w + 4 * q]);
+    wgT[4 * q] = f32x2{v0.x, v1.x}; wgT[4 * q + 1] = f32x2{v0.y, v1.y};
+    wgT[4 * q + 2] = f32x2{v0.z, v1.z}; wgT[4 * q + 3] = f32x2{v0.w, v1.w};
   }
   float tv[NTV], gtv[NTV];
 #pragma unroll
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
 
   float dh = (tid < D && steps > 0) ? p.d_short[(size_t)b * D + tid] : 0.f;
 
-  float n_r = 0.f, n_u = 0.f, n_c = 0.f, n_T = 0.f, n_hp = 0.f, n_x = 0.f, n_dl = 0.f;
+  float n_r = 0.f, n_u = 0.f, n_c = 0.f, n_T = 0.f, n_hp = 0.f, n_x = 0.f, n_dl = 0.f, n_dx = 0.f;
   auto prefetch = [&](int t) {
     if (tid < D) {
       const size_t r = row0 + t;
@@ -212,12 +221,13 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
       n_r = sv[0]; n_u = sv[D]; n_c = sv[2 * D]; n_T = sv[3 * D]; n_hp = sv[4 * D];
       n_x = p.x[r * D + tid];
       n_dl = p.timelast[r];
+      n_dx = p.d_x[r * D + tid];     // read-modify-write operand fetched a step ahead (only this thread writes it)
     }
   };
   if (steps > 0) prefetch(steps - 1);
 
   for (int t = steps - 1; t >= 0; --t) {
-    const float r_ = n_r, u = n_u, c = n_c, T = n_T, hp = n_hp, xt = n_x, dl = n_dl;
+    const float r_ = n_r, u = n_u, c = n_c, T = n_T, hp = n_hp, xt = n_x, dl = n_dl, dx_old = n_dx;
     if (t > 0) prefetch(t - 1);
     const size_t row = row0 + t;
     float du = 0.f, dhp = 0.f, dcpre = 0.f;
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
       gtv[HW1] += dtw * hp;
       gtv[W1] += dts * dl;
       gtv[B1] += dts;
-      p.d_x[row * D + tid] += dtw * tv[KW1];
+      p.d_x[row * D + tid] = dx_old + dtw * tv[KW1];
       dhp += dtw * tv[HW1];
     }
     __syncthreads();
@@ -255,13 +265,10 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
         const float4 v = *reinterpret_cast<const float4 *>(&dc_s[16 * w + 4 * q]);
         dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
       }
-      float acc[2] = {0.f, 0.f};
+      f32x2 acc = {0.f, 0.f};
 #pragma unroll
-      for (int nn = 0; nn < 16; ++nn)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = fmaf(dv[nn], wcT[nn][j], acc[j]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) pA[w][lane + 64 * j] = acc[j];
+      for (int nn = 0; nn < 16; ++nn) acc = pk_fma(f32x2{dv[nn], dv[nn]}, wcT[nn], acc);
+      pA[w][lane] = acc.x; pA[w][lane + 64] = acc.y;
     }
     __syncthreads();
     if (tid < D) {
@@ -287,13 +294,10 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
         const float4 v = *reinterpret_cast<const float4 *>(&dg_s[32 * w + 4 * q]);
         dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
       }
-      float acc[2] = {0.f, 0.f};
+      f32x2 acc = {0.f, 0.f};
 #pragma unroll
-      for (int nn = 0; nn < 32; ++nn)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = fmaf(dv[nn], wgT[nn][j], acc[j]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) pB[w][lane + 64 * j] = acc[j];
+      for (int nn = 0; nn < 32; ++nn) acc = pk_fma(f32x2{dv[nn], dv[nn]}, wgT[nn], acc);
+      pB[w][lane] = acc.x; pB[w][lane + 64] = acc.y;
     }
     __syncthreads();
     if (tid < D) {
