@@ -57,6 +57,8 @@ const char *mtam_arch(void);     /* "gfx950" */
  *   MTAM_EPI_ACCUM       C += acc
  *   MTAM_EPI_ACCUM_MASK  C += acc; aux_out = (aux_in[m,n] > 0) ? C : 0
  *   MTAM_EPI_ATOMIC      atomicAdd(C, acc)   (split_k >= 1 slices of K)
+ *   MTAM_EPI_ACCUM2_MASK C += acc + add2[m,n]; aux_out = (aux_in[m,n] > 0) ? C : 0
+ *                        (add2 is passed in the `bias` argument as an [M, ld_aux] matrix)
  * aux_in / aux_out share ld_aux.  split_k > 1 is only valid with ATOMIC.
  */
 enum {
@@ -66,7 +68,8 @@ enum {
   MTAM_EPI_RELU_ADD = 3,
   MTAM_EPI_ACCUM = 4,
   MTAM_EPI_ACCUM_MASK = 5,
-  MTAM_EPI_ATOMIC = 6
+  MTAM_EPI_ATOMIC = 6,
+  MTAM_EPI_ACCUM2_MASK = 7
 };
 int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
                   const float *A, int lda, const float *B, int ldb,
@@ -164,13 +167,13 @@ int mtam_tagru_fwd(const float *xproj, const float *x, const float *timelast,
  *   d_short [B, D]  gradient of short_out
  *   d_xproj [B*L, 3D] out: d(gate pre-act) | d(candidate pre-act), zero for dead steps
  *   rh      [B*L, D] out: r * h_prev (A operand of the candidate-kernel gradient)
- *   d_x     [B*L, D] in/out: += the time-gate path (dtw * _time_kernel_w1)
+ *   d_xt    [B*L, D] out: the time-gate path of d loss / d x (dtw * _time_kernel_w1), zero for dead steps
  *   d_tvec_partial [B, 8, D] out: per-sample gradients of tvec (caller column-sums)
  */
 int mtam_tagru_bwd(const float *d_short, const float *x, const float *timelast,
                    const int32_t *seq_len, const float *wh_g, const float *wh_c,
                    const float *tvec, const float *save, int B, int L,
-                   float *d_xproj, float *rh, float *d_x, float *d_tvec_partial,
+                   float *d_xproj, float *rh, float *d_xt, float *d_tvec_partial,
                    void *stream);
 
 /* ------------------------------------------ time-aware attention, T_q = 1

@@ -39,6 +39,14 @@ def _chunks(seq, n):
         yield seq[i:i + n]
 
 
+class _Inline(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 class _Batch(object):
     """Per-batch-size device buffers (activations, gradients, saved state)."""
 
@@ -81,7 +89,7 @@ class _Batch(object):
         # backward
         self.d_dec = [f(B, D) for _ in range(NB + 1)]
         self.d_kv = f(R, 2 * NB * D)
-        self.d_x, self.d_z = f(R, D), f(R, D)
+        self.d_x, self.d_z, self.d_xt = f(R, D), f(R, D), f(R, D)
         self.d_qt = [f(B, 2 * D) for _ in range(NB)]
         self.d_tp_partial = [f(B, 5 * L) for _ in range(NB)]
         self.d_ln_partial = [f(B, 2 * D) for _ in range(NB)]
@@ -146,6 +154,13 @@ class TimeAwarePath(object):
         self.adam_state = torch.tensor([0.0, 0.9, 0.999, 1e-8, 0.9, 0.999, 0.0, 0.0], dtype=torch.float32,
                                        device=dev)
         self._batches = {}
+        # side streams: independent branches of the step (K/V projection next to the GRU, the dense
+        # item gradient and the weight-gradient GEMMs next to the serial backward chain) run
+        # concurrently; under hipGraph capture the waits become graph edges.
+        # Measured on MI355X at B=128: 388 us/step with the branches on side streams vs 366 us in one
+        # stream -- the cross-queue graph edges cost more than the overlap wins -- so it is off by default.
+        self.side = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        self.overlap = False
         self.allreduce_fn = None        # set by data_parallel.attach()
         self.world_size = 1             # the loss is a mean over world_size * B samples
 
@@ -178,6 +193,22 @@ class TimeAwarePath(object):
         self.fill_host(bt, feed, lr)
         return bt.host_arena.to(self.device, non_blocking=False)
 
+    # ------------------------------------------------------------ stream plumbing
+    def _fork(self, i):
+        """Run the following `with` block on side stream i, ordered after everything enqueued so far
+        on the current stream.  With overlap disabled the block simply runs in line."""
+        if not self.overlap:
+            return _Inline()
+        side = self.side[i]
+        side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(side)
+
+    def _join(self, *idx):
+        if self.overlap:
+            cur = torch.cuda.current_stream()
+            for i in idx:
+                cur.wait_stream(self.side[i])
+
     # ----------------------------------------------------------------- forward
     def forward(self, bt, training=True):
         B, R, L, NB, H = bt.B, bt.R, self.L, self.NB, self.H
@@ -186,11 +217,13 @@ class TimeAwarePath(object):
                            fd["category_list"], fd["position_list"], fd["user_id"], B, L, 1,
                            bt.ic, bt.pos, bt.user, bt.l2_partial)
         ops.gemm(bt.ic, self.seg("dense4emb/w"), bt.x, epilogue=ops.EPI_RELU_ADD, aux_in=bt.pos, aux_out=bt.zr)
+        with self._fork(0):          # keys/values of every block: independent of the GRU
+            ops.gemm(bt.x, self.seg("kv/w"), bt.kv, epilogue=ops.EPI_BIAS_RELU, bias=self.seg("kv/b"))
         ops.gemm(bt.x, self.seg("gru/wx"), bt.xproj, epilogue=ops.EPI_BIAS, bias=self.seg("gru/bx"))
         ops.tagru_fwd(bt.xproj, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
                       self.seg("gru/wh_c"), self.seg("gru/tvec"), B, L, bt.hs, bt.short,
                       bt.gru_save if training else None)
-        ops.gemm(bt.x, self.seg("kv/w"), bt.kv, epilogue=ops.EPI_BIAS_RELU, bias=self.seg("kv/b"))
+        self._join(0)
         for i in range(NB):
             ln = self.seg("blk%d/ln" % i)
             ops.ta_attn_decode_fwd(bt.dec[i], bt.x, bt.kv, 2 * NB * D, 2 * i * D, (2 * i + 1) * D,
@@ -216,12 +249,18 @@ class TimeAwarePath(object):
         fd, T, G = bt.feed, self.tables, self.grads
         gseg = lambda name: self.layout.view(G, name)
         part = bt.norm_partial
+        sr = max(1, min(16, R // 256))
+        prob = lambda A, lda, Bm, ldb, name, M, N, K, s: dict(A=A, lda=lda, B=Bm, ldb=ldb, C=gseg(name),
+                                                              ldc=N, M=M, N=N, K=K, split_k=s)
         self.zero_prefix.zero_()
-        # scoring: dE = G^T pred (dense, every row), d_pred = G E
-        ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
-        if self.tf_compat:
-            ops.sqnorm_partial(self.g_tab["item"], self.g_tab["item"].numel(), part[self.nb_dense:])
         bt.d_pred.zero_()
+        # Side 1: dense item gradient dE = G^T pred (every row) and its share of the TF global norm.
+        # Only the scatter at the very end needs it.
+        with self._fork(1):
+            ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
+            if self.tf_compat:
+                ops.sqnorm_partial(self.g_tab["item"], self.g_tab["item"].numel(), part[self.nb_dense:])
+        # Main chain: d_pred = G E -> head LN -> decoder blocks (last to first)
         split_v = max(1, min(64, (self.item_rows + 127) // 128))
         ops.gemm(bt.logits, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v)
         ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_dec[NB], gseg("head/ln"))
@@ -233,44 +272,50 @@ class TimeAwarePath(object):
                                    ln[1], bt.attn_save[i], B, L, H, 0 if i == NB - 1 else 1,
                                    bt.d_dec[i], bt.d_kv, bt.d_x, bt.d_qt[i], bt.d_tp_partial[i],
                                    bt.d_ln_partial[i])
-        # keys/values: d_x += d_kv . Wkv^T
-        ops.gemm(bt.d_kv, self.seg("kv/w"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM)
-        # GRU back through time, then d_x += d_xproj . Wx^T and d_z = d_x masked by relu(z) > 0
+        # Side 2: what only needs the attention gradients -- d_x += d_kv . Wkv^T, then dWkv, dWqt and
+        # the attention bias-like gradients -- runs next to the GRU's backward-through-time.
+        with self._fork(2):
+            ops.gemm(bt.d_kv, self.seg("kv/w"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM)
+            problems = [prob(bt.x, D, bt.d_kv, 2 * NB * D, "kv/w", D, 2 * NB * D, R, sr)] + \
+                [prob(bt.dec[i], D, bt.d_qt[i], 2 * D, "blk%d/wqt" % i, D, 2 * D, B, 1) for i in range(NB)]
+            for chunk in _chunks(problems, MAX_GROUP):
+                ops.gemm_tn_atomic_grouped(chunk)
+            jobs = [(bt.d_kv, R, 2 * NB * D, 2 * NB * D, gseg("kv/b"))]
+            for i in range(NB):
+                jobs += [(bt.d_qt[i], B, D, 2 * D, gseg("blk%d/bq" % i)),
+                         (bt.d_tp_partial[i], B, 5 * L, 5 * L, gseg("blk%d/tparams" % i).view(-1)),
+                         (bt.d_ln_partial[i], B, 2 * D, 2 * D, gseg("blk%d/ln" % i).view(-1))]
+            for chunk in _chunks(jobs, MAX_GROUP):
+                ops.colsum_atomic_multi(chunk)
+        # Main: GRU back through time (its time-gate path goes to d_xt, not into d_x, so that it does
+        # not race with side 2's accumulation into d_x)
         ops.tagru_bwd(bt.d_dec[0], bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
                       self.seg("gru/wh_c"), self.seg("gru/tvec"), bt.gru_save, B, L, bt.d_xproj, bt.rh,
-                      bt.d_x, bt.d_tvec_partial)
-        ops.gemm(bt.d_xproj, self.seg("gru/wx"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM_MASK,
-                 aux_in=bt.zr, aux_out=bt.d_z)
+                      bt.d_xt, bt.d_tvec_partial)
+        # Side 3: GRU weight gradients and bias-like gradients
+        with self._fork(3):
+            problems = [
+                prob(bt.x, D, bt.d_xproj, 3 * D, "gru/wx", D, 3 * D, R, sr),
+                prob(bt.gru_save.view(-1)[4 * D:], 5 * D, bt.d_xproj, 3 * D, "gru/wh_g", D, 2 * D, R, sr),
+                prob(bt.rh, D, bt.d_xproj.view(-1)[2 * D:], 3 * D, "gru/wh_c", D, D, R, sr)]
+            ops.gemm_tn_atomic_grouped(problems)
+            ops.colsum_atomic_multi([(bt.d_xproj, R, 3 * D, 3 * D, gseg("gru/bx")),
+                                     (bt.d_tvec_partial, B, 8 * D, 8 * D, gseg("gru/tvec").view(-1))])
+        # Main: d_x += d_xproj . Wx^T + d_xt, d_z = d_x where relu(z) > 0; then d[item|cat] and dW4
+        self._join(2)
+        ops.gemm(bt.d_xproj, self.seg("gru/wx"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM2_MASK,
+                 bias=bt.d_xt, aux_in=bt.zr, aux_out=bt.d_z)
+        with self._fork(2):
+            ops.gemm_tn_atomic_grouped([prob(bt.ic, 2 * D, bt.d_z, D, "dense4emb/w", 2 * D, D, R, sr)])
         ops.gemm(bt.d_z, self.seg("dense4emb/w"), bt.d_ic, trans_b=True)
-        # every weight gradient dW = A^T B in one grouped split-K launch
-        sr = max(1, min(16, R // 256))
-        prob = lambda A, lda, Bm, ldb, name, M, N, K, s: dict(A=A, lda=lda, B=Bm, ldb=ldb, C=gseg(name),
-                                                              ldc=N, M=M, N=N, K=K, split_k=s)
-        problems = [
-            prob(bt.x, D, bt.d_xproj, 3 * D, "gru/wx", D, 3 * D, R, sr),
-            prob(bt.x, D, bt.d_kv, 2 * NB * D, "kv/w", D, 2 * NB * D, R, sr),
-            prob(bt.ic, 2 * D, bt.d_z, D, "dense4emb/w", 2 * D, D, R, sr),
-            prob(bt.gru_save.view(-1)[4 * D:], 5 * D, bt.d_xproj, 3 * D, "gru/wh_g", D, 2 * D, R, sr),
-            prob(bt.rh, D, bt.d_xproj.view(-1)[2 * D:], 3 * D, "gru/wh_c", D, D, R, sr),
-        ] + [prob(bt.dec[i], D, bt.d_qt[i], 2 * D, "blk%d/wqt" % i, D, 2 * D, B, 1) for i in range(NB)]
-        for chunk in _chunks(problems, MAX_GROUP):
-            ops.gemm_tn_atomic_grouped(chunk)
-        # every bias-like gradient (column sums of per-row / per-sample partials) in one launch
-        jobs = [(bt.d_xproj, R, 3 * D, 3 * D, gseg("gru/bx")),
-                (bt.d_kv, R, 2 * NB * D, 2 * NB * D, gseg("kv/b")),
-                (bt.d_tvec_partial, B, 8 * D, 8 * D, gseg("gru/tvec").view(-1))]
-        for i in range(NB):
-            jobs += [(bt.d_qt[i], B, D, 2 * D, gseg("blk%d/bq" % i)),
-                     (bt.d_tp_partial[i], B, 5 * L, 5 * L, gseg("blk%d/tparams" % i).view(-1)),
-                     (bt.d_ln_partial[i], B, 2 * D, 2 * D, gseg("blk%d/ln" % i).view(-1))]
-        for chunk in _chunks(jobs, MAX_GROUP):
-            ops.colsum_atomic_multi(chunk)
-        # tables
+        # tables: sparse rows on top of the dense item gradient
+        self._join(1)
         slot_part = part[self.nb_dense + self.nb_item:]
         ops.emb_scatter_add_bwd(bt.d_ic, bt.d_x, bt.ic, bt.pos, bt.user, fd["item_list"], fd["category_list"],
                                 fd["position_list"], fd["user_id"], fd["seq_length"], B, L, self.reg, 1,
                                 self.g_tab["item"], self.g_tab["category"], self.g_tab["position"],
                                 self.g_tab["user"], slot_part)
+        self._join(2, 3)
 
     # ------------------------------------------------------------------ update
     def clip_and_apply(self, bt):

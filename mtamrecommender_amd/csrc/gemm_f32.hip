@@ -212,6 +212,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
       v += *c;
       *c = v;
       p.aux_out[o] = (p.aux_in[o] > 0.f) ? v : 0.f;
+    } else if (EPI == MTAM_EPI_ACCUM2_MASK) {
+      const size_t o = (size_t)gm * p.ld_aux + gn;
+      v += *c + p.bias[o];
+      *c = v;
+      p.aux_out[o] = (p.aux_in[o] > 0.f) ? v : 0.f;
     } else {  // MTAM_EPI_ATOMIC
       atomicAdd(c, v);
     }
@@ -255,6 +260,7 @@ void launch_epi(int epi, dim3 grid, hipStream_t s, const GemmArgs &a) {
     case MTAM_EPI_RELU_ADD: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_RELU_ADD>), grid, dim3(256), 0, s, a); break;
     case MTAM_EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ACCUM>), grid, dim3(256), 0, s, a); break;
     case MTAM_EPI_ACCUM_MASK: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ACCUM_MASK>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_ACCUM2_MASK: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ACCUM2_MASK>), grid, dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ATOMIC>), grid, dim3(256), 0, s, a); break;
   }
 }
@@ -267,13 +273,13 @@ extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, cons
                              int split_k, void *stream) {
   MTAM_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive (got %d %d %d)", M, N, K);
   MTAM_CHECK_ARG(A && B && C, "gemm: null operand");
-  MTAM_CHECK_ARG(epilogue >= MTAM_EPI_STORE && epilogue <= MTAM_EPI_ATOMIC, "gemm: bad epilogue %d", epilogue);
+  MTAM_CHECK_ARG(epilogue >= MTAM_EPI_STORE && epilogue <= MTAM_EPI_ACCUM2_MASK, "gemm: bad epilogue %d", epilogue);
   MTAM_CHECK_ARG(lda >= (trans_a ? M : K), "gemm: lda %d too small", lda);
   MTAM_CHECK_ARG(ldb >= (trans_b ? K : N), "gemm: ldb %d too small", ldb);
   MTAM_CHECK_ARG(ldc >= N, "gemm: ldc %d too small", ldc);
-  if (epilogue == MTAM_EPI_BIAS || epilogue == MTAM_EPI_BIAS_RELU)
+  if (epilogue == MTAM_EPI_BIAS || epilogue == MTAM_EPI_BIAS_RELU || epilogue == MTAM_EPI_ACCUM2_MASK)
     MTAM_CHECK_ARG(bias != nullptr, "gemm: bias epilogue without bias");
-  if (epilogue == MTAM_EPI_RELU_ADD || epilogue == MTAM_EPI_ACCUM_MASK)
+  if (epilogue == MTAM_EPI_RELU_ADD || epilogue == MTAM_EPI_ACCUM_MASK || epilogue == MTAM_EPI_ACCUM2_MASK)
     MTAM_CHECK_ARG(aux_in && aux_out && ld_aux >= N, "gemm: aux epilogue needs aux_in/aux_out/ld_aux");
   if (split_k < 1) split_k = 1;
   MTAM_CHECK_ARG(split_k == 1 || epilogue == MTAM_EPI_ATOMIC, "gemm: split_k > 1 needs the atomic epilogue");

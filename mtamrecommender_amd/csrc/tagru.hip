@@ -165,7 +165,7 @@ struct BwdArgs {
   const int32_t *seq_len;
   const float *wh_g, *wh_c, *tvec, *save;
   int B, L;
-  float *d_xproj, *rh, *d_x, *d_tvec_partial;
+  float *d_xproj, *rh, *d_xt, *d_tvec_partial;
 };
 
 __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
@@ -208,12 +208,15 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
   for (int t = steps; t < p.L; ++t) {
     const size_t r = row0 + t;
     if (tid < 3 * D) p.d_xproj[r * (3 * D) + tid] = 0.f;
-    if (tid < D) p.rh[r * D + tid] = 0.f;
+    if (tid < D) {
+      p.rh[r * D + tid] = 0.f;
+      p.d_xt[r * D + tid] = 0.f;
+    }
   }
 
   float dh = (tid < D && steps > 0) ? p.d_short[(size_t)b * D + tid] : 0.f;
 
-  float n_r = 0.f, n_u = 0.f, n_c = 0.f, n_T = 0.f, n_hp = 0.f, n_x = 0.f, n_dl = 0.f, n_dx = 0.f;
+  float n_r = 0.f, n_u = 0.f, n_c = 0.f, n_T = 0.f, n_hp = 0.f, n_x = 0.f, n_dl = 0.f;
   auto prefetch = [&](int t) {
     if (tid < D) {
       const size_t r = row0 + t;
@@ -221,13 +224,12 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
       n_r = sv[0]; n_u = sv[D]; n_c = sv[2 * D]; n_T = sv[3 * D]; n_hp = sv[4 * D];
       n_x = p.x[r * D + tid];
       n_dl = p.timelast[r];
-      n_dx = p.d_x[r * D + tid];     // read-modify-write operand fetched a step ahead (only this thread writes it)
     }
   };
   if (steps > 0) prefetch(steps - 1);
 
   for (int t = steps - 1; t >= 0; --t) {
-    const float r_ = n_r, u = n_u, c = n_c, T = n_T, hp = n_hp, xt = n_x, dl = n_dl, dx_old = n_dx;
+    const float r_ = n_r, u = n_u, c = n_c, T = n_T, hp = n_hp, xt = n_x, dl = n_dl;
     if (t > 0) prefetch(t - 1);
     const size_t row = row0 + t;
     float du = 0.f, dhp = 0.f, dcpre = 0.f;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
       gtv[HW1] += dtw * hp;
       gtv[W1] += dts * dl;
       gtv[B1] += dts;
-      p.d_x[row * D + tid] = dx_old + dtw * tv[KW1];
+      p.d_xt[row * D + tid] = dtw * tv[KW1];
       dhp += dtw * tv[HW1];
     }
     __syncthreads();
@@ -331,13 +333,13 @@ extern "C" int mtam_tagru_fwd(const float *xproj, const float *x, const float *t
 extern "C" int mtam_tagru_bwd(const float *d_short, const float *x, const float *timelast,
                               const int32_t *seq_len, const float *wh_g, const float *wh_c,
                               const float *tvec, const float *save, int B, int L, float *d_xproj,
-                              float *rh, float *d_x, float *d_tvec_partial, void *stream) {
+                              float *rh, float *d_xt, float *d_tvec_partial, void *stream) {
   MTAM_CHECK_ARG(B > 0 && L > 0, "tagru_bwd: B and L must be positive");
   MTAM_CHECK_ARG(d_short && x && timelast && seq_len && wh_g && wh_c && tvec && save && d_xproj && rh &&
-                     d_x && d_tvec_partial,
+                     d_xt && d_tvec_partial,
                  "tagru_bwd: null argument");
   MTAM_CHECK_ARG(mtam_aligned16(wh_g) && mtam_aligned16(wh_c), "tagru_bwd: weights must be 16-byte aligned");
-  BwdArgs a{d_short, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xproj, rh, d_x, d_tvec_partial};
+  BwdArgs a{d_short, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xproj, rh, d_xt, d_tvec_partial};
   hipLaunchKernelGGL(tagru_bwd_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("tagru_bwd");
   return MTAM_OK;

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-EPI_STORE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_ADD, EPI_ACCUM, EPI_ACCUM_MASK, EPI_ATOMIC = range(7)
+EPI_STORE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_ADD, EPI_ACCUM, EPI_ACCUM_MASK, EPI_ATOMIC, EPI_ACCUM2_MASK = range(8)
 D = 128
 
 
