@@ -239,6 +239,16 @@ int mtam_softmax_ce(const float *logits, int ld, const int32_t *target, int B, i
 int mtam_loss_reduce(const float *l2_partial, int n_l2, const float *ce, int B, float reg,
                      float ce_scale, float *loss, void *stream);
 
+/* mtam_softmax_ce + mtam_loss_reduce in one call; for V <= 16384 also in ONE launch (a workgroup
+ * per row keeps the row in registers, the last workgroup to finish reduces the loss).
+ * partial: mtam_softmax_ce_partials(B, V) + 4 floats, ZEROED ONCE by the caller before the first
+ * call (its first word is an arrival ticket that the kernel resets itself).  loss == NULL: no loss
+ * reduction here (mtam_sqnorm_clip_scale can do it at the end of the step instead). */
+int mtam_softmax_ce_loss(const float *logits, int ld, const int32_t *target, int B, int V,
+                         float grad_scale, float *lse, float *ce, float *d_logits, float *partial,
+                         const float *l2_partial, int n_l2, float reg, float ce_scale, float *loss,
+                         void *stream);
+
 /* ------------------------------------------------------------------ top-K
  * tf.nn.top_k (Model/base_model.py:196-200): for every row the k largest
  * scores, descending, equal values -> lower index first.  k <= 64.
@@ -270,6 +280,14 @@ int mtam_sqnorm_blocks(size_t n);
 int mtam_sqnorm_partial(const float *g, size_t n, float *partial, void *stream);
 int mtam_clip_scale(const float *partials, int n_partials, float clip_norm, float *scale,
                     const float *lr, float *adam_state, void *stream);
+/* mtam_sqnorm_partial(g -> partials[offset...]) and mtam_clip_scale over partials[0 .. n_total) in ONE
+ * launch (the last workgroup to finish does the reduction).  ticket: one device word, zero on the
+ * first call, reset by the kernel.  With `loss` given the same workgroup also does mtam_loss_reduce
+ * (the step's reported loss), so a training step needs no separate loss launch. */
+int mtam_sqnorm_clip_scale(const float *g, size_t n, float *partials, int offset, int n_total,
+                           float clip_norm, float *scale, const float *lr, float *adam_state,
+                           unsigned int *ticket, const float *l2_partial, int n_l2, const float *ce,
+                           int B, float reg, float ce_scale, float *loss, void *stream);
 int mtam_adam_block(void);
 int mtam_adam(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
               const float *hyper, size_t sparse_begin, void *stream);

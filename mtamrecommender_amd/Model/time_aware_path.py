@@ -83,7 +83,7 @@ class _Batch(object):
         self.pred, self.ln_save = f(B, D), f(B, D + 1)
         self.logits = f(B, V)
         self.lse, self.ce = f(B), f(B)
-        self.ce_partial = f(ops.softmax_ce_partials(B, V))
+        self.ce_partial = torch.zeros(ops.softmax_ce_partials(B, V) + 4, dtype=torch.float32, device=dev)
         self.l2_partial = f(ops.emb_gather_partials(B, L))
         self.loss = f(3)
         # backward
@@ -150,6 +150,7 @@ class TimeAwarePath(object):
         self.nb_item = ops.sqnorm_blocks(self.tables["item"].numel())
         self.nb_all = max(ops.sqnorm_blocks(self.n_total), self.nb_dense + self.nb_item)
         self.scale = z(2)
+        self.ticket = torch.zeros(4, dtype=torch.int32, device=dev)
         # Adam state on the device: [lr_t, beta1, beta2, eps, beta1_power, beta2_power, -, -]
         self.adam_state = torch.tensor([0.0, 0.9, 0.999, 1e-8, 0.9, 0.999, 0.0, 0.0], dtype=torch.float32,
                                        device=dev)
@@ -239,9 +240,9 @@ class TimeAwarePath(object):
         B, V = bt.B, self.item_rows
         gb = B * self.world_size
         # logits -> lse, ce; then d_logits in place
-        ops.softmax_ce(bt.logits, V, bt.feed["target_item_id"], B, V, 1.0 / gb, bt.lse, bt.ce, bt.logits,
-                       bt.ce_partial)
-        ops.loss_reduce(bt.l2_partial, bt.l2_partial.numel(), bt.ce, B, self.reg, 1.0 / gb, bt.loss)
+        # the loss scalar itself is reduced in the step epilogue (clip_and_apply), off the chain
+        ops.softmax_ce_loss(bt.logits, V, bt.feed["target_item_id"], B, V, 1.0 / gb, bt.lse, bt.ce, bt.logits,
+                            bt.ce_partial, bt.l2_partial, bt.l2_partial.numel(), self.reg, 1.0 / gb, None)
 
     # ---------------------------------------------------------------- backward
     def backward(self, bt):
@@ -272,42 +273,52 @@ class TimeAwarePath(object):
                                    ln[1], bt.attn_save[i], B, L, H, 0 if i == NB - 1 else 1,
                                    bt.d_dec[i], bt.d_kv, bt.d_x, bt.d_qt[i], bt.d_tp_partial[i],
                                    bt.d_ln_partial[i])
-        # Side 2: what only needs the attention gradients -- d_x += d_kv . Wkv^T, then dWkv, dWqt and
-        # the attention bias-like gradients -- runs next to the GRU's backward-through-time.
-        with self._fork(2):
-            ops.gemm(bt.d_kv, self.seg("kv/w"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM)
-            problems = [prob(bt.x, D, bt.d_kv, 2 * NB * D, "kv/w", D, 2 * NB * D, R, sr)] + \
-                [prob(bt.dec[i], D, bt.d_qt[i], 2 * D, "blk%d/wqt" % i, D, 2 * D, B, 1) for i in range(NB)]
+        kv_problems = [prob(bt.x, D, bt.d_kv, 2 * NB * D, "kv/w", D, 2 * NB * D, R, sr)] + \
+            [prob(bt.dec[i], D, bt.d_qt[i], 2 * D, "blk%d/wqt" % i, D, 2 * D, B, 1) for i in range(NB)]
+        kv_jobs = [(bt.d_kv, R, 2 * NB * D, 2 * NB * D, gseg("kv/b"))]
+        for i in range(NB):
+            kv_jobs += [(bt.d_qt[i], B, D, 2 * D, gseg("blk%d/bq" % i)),
+                        (bt.d_tp_partial[i], B, 5 * L, 5 * L, gseg("blk%d/tparams" % i).view(-1)),
+                        (bt.d_ln_partial[i], B, 2 * D, 2 * D, gseg("blk%d/ln" % i).view(-1))]
+        gru_problems = [
+            prob(bt.x, D, bt.d_xproj, 3 * D, "gru/wx", D, 3 * D, R, sr),
+            prob(bt.gru_save.view(-1)[4 * D:], 5 * D, bt.d_xproj, 3 * D, "gru/wh_g", D, 2 * D, R, sr),
+            prob(bt.rh, D, bt.d_xproj.view(-1)[2 * D:], 3 * D, "gru/wh_c", D, D, R, sr)]
+        gru_jobs = [(bt.d_xproj, R, 3 * D, 3 * D, gseg("gru/bx")),
+                    (bt.d_tvec_partial, B, 8 * D, 8 * D, gseg("gru/tvec").view(-1))]
+        w4_problem = [prob(bt.ic, 2 * D, bt.d_z, D, "dense4emb/w", 2 * D, D, R, sr)]
+
+        def grouped(problems, jobs):
             for chunk in _chunks(problems, MAX_GROUP):
                 ops.gemm_tn_atomic_grouped(chunk)
-            jobs = [(bt.d_kv, R, 2 * NB * D, 2 * NB * D, gseg("kv/b"))]
-            for i in range(NB):
-                jobs += [(bt.d_qt[i], B, D, 2 * D, gseg("blk%d/bq" % i)),
-                         (bt.d_tp_partial[i], B, 5 * L, 5 * L, gseg("blk%d/tparams" % i).view(-1)),
-                         (bt.d_ln_partial[i], B, 2 * D, 2 * D, gseg("blk%d/ln" % i).view(-1))]
             for chunk in _chunks(jobs, MAX_GROUP):
                 ops.colsum_atomic_multi(chunk)
+
+        # Side 2: what only needs the attention gradients -- d_x += d_kv . Wkv^T, then dWkv, dWqt and
+        # the attention bias-like gradients -- may run next to the GRU's backward-through-time.
+        with self._fork(2):
+            ops.gemm(bt.d_kv, self.seg("kv/w"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM)
+            if self.overlap:
+                grouped(kv_problems, kv_jobs)
         # Main: GRU back through time (its time-gate path goes to d_xt, not into d_x, so that it does
         # not race with side 2's accumulation into d_x)
         ops.tagru_bwd(bt.d_dec[0], bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
                       self.seg("gru/wh_c"), self.seg("gru/tvec"), bt.gru_save, B, L, bt.d_xproj, bt.rh,
                       bt.d_xt, bt.d_tvec_partial)
-        # Side 3: GRU weight gradients and bias-like gradients
-        with self._fork(3):
-            problems = [
-                prob(bt.x, D, bt.d_xproj, 3 * D, "gru/wx", D, 3 * D, R, sr),
-                prob(bt.gru_save.view(-1)[4 * D:], 5 * D, bt.d_xproj, 3 * D, "gru/wh_g", D, 2 * D, R, sr),
-                prob(bt.rh, D, bt.d_xproj.view(-1)[2 * D:], 3 * D, "gru/wh_c", D, D, R, sr)]
-            ops.gemm_tn_atomic_grouped(problems)
-            ops.colsum_atomic_multi([(bt.d_xproj, R, 3 * D, 3 * D, gseg("gru/bx")),
-                                     (bt.d_tvec_partial, B, 8 * D, 8 * D, gseg("gru/tvec").view(-1))])
-        # Main: d_x += d_xproj . Wx^T + d_xt, d_z = d_x where relu(z) > 0; then d[item|cat] and dW4
+        if self.overlap:
+            with self._fork(3):          # GRU weight and bias-like gradients
+                grouped(gru_problems, gru_jobs)
+        # Main: d_x += d_xproj . Wx^T + d_xt, d_z = d_x where relu(z) > 0; then d[item|cat]
         self._join(2)
         ops.gemm(bt.d_xproj, self.seg("gru/wx"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM2_MASK,
                  bias=bt.d_xt, aux_in=bt.zr, aux_out=bt.d_z)
-        with self._fork(2):
-            ops.gemm_tn_atomic_grouped([prob(bt.ic, 2 * D, bt.d_z, D, "dense4emb/w", 2 * D, D, R, sr)])
+        if self.overlap:
+            with self._fork(2):
+                grouped(w4_problem, [])
         ops.gemm(bt.d_z, self.seg("dense4emb/w"), bt.d_ic, trans_b=True)
+        if not self.overlap:
+            # one stream: every weight gradient in ONE grouped launch, every bias-like one in ONE launch
+            grouped(gru_problems + kv_problems + w4_problem, gru_jobs + kv_jobs)
         # tables: sparse rows on top of the dense item gradient
         self._join(1)
         slot_part = part[self.nb_dense + self.nb_item:]
@@ -322,12 +333,14 @@ class TimeAwarePath(object):
         part = bt.norm_partial
         if self.tf_compat:
             # dense variables + [item dense (measured before the scatter) + un-deduplicated slots]
-            ops.sqnorm_partial(self.flat_g, self.n_dense, part)
-            n = self.nb_dense + self.nb_item + bt.n_slot
+            n_g, n = self.n_dense, self.nb_dense + self.nb_item + bt.n_slot
         else:
-            ops.sqnorm_partial(self.flat_g, self.n_total, part)
+            n_g = self.n_total
             n = ops.sqnorm_blocks(self.n_total)
-        ops.clip_scale(part, n, self.clip, self.scale, bt.feed["lr"], self.adam_state)
+        gb = bt.B * self.world_size
+        ops.sqnorm_clip_scale(self.flat_g, n_g, part, 0, n, self.clip, self.scale, bt.feed["lr"],
+                              self.adam_state, self.ticket, bt.l2_partial, bt.l2_partial.numel(), bt.ce, bt.B,
+                              self.reg, 1.0 / gb, bt.loss)
         ops.adam(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,
                  self.adam_state, self.n_dense)
 

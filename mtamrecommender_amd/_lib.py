@@ -39,10 +39,14 @@ SIGNATURES = {
     "mtam_softmax_ce_partials": (c_int, [c_int, c_int]),
     "mtam_softmax_ce": (c_int, [P, c_int, P, c_int, c_int, c_float, P, P, P, P, P]),
     "mtam_loss_reduce": (c_int, [P, c_int, P, c_int, c_float, c_float, P, P]),
+    "mtam_softmax_ce_loss": (c_int, [P, c_int, P, c_int, c_int, c_float, P, P, P, P, P, c_int, c_float, c_float,
+                                     P, P]),
     "mtam_topk": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     "mtam_sqnorm_blocks": (c_int, [c_size_t]),
     "mtam_sqnorm_partial": (c_int, [P, c_size_t, P, P]),
     "mtam_clip_scale": (c_int, [P, c_int, c_float, P, P, P, P]),
+    "mtam_sqnorm_clip_scale": (c_int, [P, c_size_t, P, c_int, c_int, c_float, P, P, P, P, P, c_int, P, c_int,
+                                       c_float, c_float, P, P]),
     "mtam_adam_block": (c_int, []),
     "mtam_adam": (c_int, [P, P, P, P, c_size_t, P, P, c_size_t, P]),
     "mtam_gemm_tn_atomic_grouped": (c_int, [c_int, P, P]),

@@ -57,6 +57,92 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(const float *__restrict
   }
 }
 
+// sqnorm + clip_scale in one launch: every workgroup writes its partial; the last one to arrive
+// (agent-scope ticket; partials moved by sc1 stores / sc1 loads) sums ALL partials and does what
+// clip_scale_kernel does.  `ticket` must be zero on entry and is left zero.
+__global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restrict__ g, size_t n,
+                                                          float *__restrict__ partials, int offset,
+                                                          int n_total, float clip, float *__restrict__ scale,
+                                                          const float *__restrict__ lr,
+                                                          float *__restrict__ adam_state, unsigned int *ticket,
+                                                          const float *__restrict__ l2_partial, int n_l2,
+                                                          const float *__restrict__ ce, int B, float reg,
+                                                          float ce_scale, float *__restrict__ loss) {
+  __shared__ float red[4];
+  __shared__ double dred[4];
+  __shared__ int s_last;
+  const size_t base = (size_t)blockIdx.x * NORM_BLOCK;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_BLOCK / 1024; ++i) {
+    const size_t o = base + (size_t)(threadIdx.x + 256 * i) * 4;
+    if (o + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4 *>(g + o);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (size_t q = o; q < n && q < o + 4; ++q) s += g[q] * g[q];
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // write-through (sc1) store + drain + ticket; the last workgroup reads with sc1 loads (no fences)
+    __hip_atomic_store(partials + offset + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (mine == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double t = 0.0;
+  for (int i = threadIdx.x; i < n_total; i += 256)
+    t += (double)__hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+  if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf((float)((dred[0] + dred[1]) + (dred[2] + dred[3])));
+    scale[0] = clip * fminf(1.0f / norm, 1.0f / clip);
+    scale[1] = norm;
+    if (adam_state) {
+      const float b1 = adam_state[1], b2 = adam_state[2];
+      const float b1p = adam_state[4], b2p = adam_state[5];
+      adam_state[0] = lr[0] * sqrtf(1.0f - b2p) / (1.0f - b1p);
+      adam_state[4] = b1p * b1;
+      adam_state[5] = b2p * b2;
+    }
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (loss) {
+    // step epilogue: the reported loss (Model/base_model.py:322-326) from the per-row cross entropies
+    // and the gather's L2 partials -- both written by earlier kernels of the step
+    double a = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < n_l2; i += 256) a += (double)l2_partial[i];
+    for (int i = threadIdx.x; i < B; i += 256) c += (double)ce[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      a += __shfl_xor(a, off, 64);
+      c += __shfl_xor(c, off, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = a;
+    __syncthreads();
+    const double l2 = 0.5 * ((dred[0] + dred[1]) + (dred[2] + dred[3]));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double ces = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+      loss[0] = (float)((double)reg * l2 + (double)ce_scale * ces);
+      loss[1] = (float)l2;
+      loss[2] = (float)(ces / (double)B);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m,
                                                    float *__restrict__ v, const float *__restrict__ g, size_t n,
                                                    const float *__restrict__ scale,
@@ -119,6 +205,24 @@ extern "C" int mtam_clip_scale(const float *partials, int n_partials, float clip
   hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partials,
                      n_partials, clip_norm, scale, lr, adam_state);
   MTAM_CHECK_LAUNCH("clip_scale");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_sqnorm_clip_scale(const float *g, size_t n, float *partials, int offset, int n_total,
+                                      float clip_norm, float *scale, const float *lr, float *adam_state,
+                                      unsigned int *ticket, const float *l2_partial, int n_l2,
+                                      const float *ce, int B, float reg, float ce_scale, float *loss,
+                                      void *stream) {
+  MTAM_CHECK_ARG(g && partials && scale && ticket && n > 0 && clip_norm > 0.f, "sqnorm_clip_scale: bad arguments");
+  MTAM_CHECK_ARG(!loss || (l2_partial && ce && B > 0 && n_l2 >= 0), "sqnorm_clip_scale: loss inputs missing");
+  MTAM_CHECK_ARG(mtam_aligned16(g), "sqnorm_clip_scale: gradient must be 16-byte aligned");
+  MTAM_CHECK_ARG((lr == nullptr) == (adam_state == nullptr), "sqnorm_clip_scale: lr and adam_state go together");
+  const int blocks = mtam_sqnorm_blocks(n);
+  MTAM_CHECK_ARG(offset >= 0 && n_total >= offset + blocks, "sqnorm_clip_scale: partial layout");
+  hipLaunchKernelGGL(sqnorm_clip_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, n,
+                     partials, offset, n_total, clip_norm, scale, lr, adam_state, ticket, l2_partial, n_l2, ce, B, reg,
+                     ce_scale, loss);
+  MTAM_CHECK_LAUNCH("sqnorm_clip_scale");
   return MTAM_OK;
 }
 

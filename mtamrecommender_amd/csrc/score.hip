@@ -158,6 +158,81 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float *__restric
   }
 }
 
+// Single-launch form for catalogs that fit one workgroup's registers (V <= 16384): one workgroup per
+// row keeps its logits in registers (max, sum-exp, gradient in one read), and the LAST workgroup to
+// finish (agent-scope ticket; payload moved by sc1 stores / sc1 loads) folds the per-row cross
+// entropies and the L2 partials into the loss.  `ticket` must be zero on entry; the
+// kernel leaves it zero.
+constexpr int CE_ROW_MAX = 64;    // logits per thread
+__global__ __launch_bounds__(256) void ce_row_loss_kernel(const float *__restrict__ logits, int ld,
+                                                          const int32_t *__restrict__ target, int B, int V,
+                                                          float grad_scale, float *__restrict__ lse,
+                                                          float *__restrict__ ce, float *__restrict__ d_logits,
+                                                          unsigned int *ticket, const float *__restrict__ l2_partial,
+                                                          int n_l2, float reg, float ce_scale,
+                                                          float *__restrict__ loss) {
+  __shared__ float red[4];
+  __shared__ int s_last;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *row = logits + (size_t)b * ld;
+  const int t = min(max(target[b], 0), V - 1);
+  const float target_logit = row[t];       // read before d_logits (which may alias logits) is written
+  float vals[CE_ROW_MAX];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < CE_ROW_MAX; ++i) {
+    const int v = tid + 256 * i;
+    vals[i] = -INFINITY;
+    if (i * 256 < V) {
+      if (v < V) vals[i] = row[v];
+      m = fmaxf(m, vals[i]);
+    }
+  }
+  m = block_reduce_max(m, red);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CE_ROW_MAX; ++i)
+    if (i * 256 < V) s += expf(vals[i] - m);
+  s = block_reduce_sum(s, red);
+  const float l = m + logf(s);
+  if (d_logits) {
+#pragma unroll
+    for (int i = 0; i < CE_ROW_MAX; ++i) {
+      const int v = tid + 256 * i;
+      if (i * 256 < V && v < V)
+        d_logits[(size_t)b * ld + v] = (expf(vals[i] - l) - (v == t ? 1.0f : 0.0f)) * grad_scale;
+    }
+  }
+  if (tid == 0) {
+    lse[b] = l;
+    // hand-off of ce[b] to whichever workgroup finishes last: write-through (sc1) store, drained,
+    // then the ticket; the reader uses sc1 loads -- no L2 write-back fence (this workgroup has just
+    // dirtied ~15 KB of gradient lines, which a release fence would have to flush first).
+    __hip_atomic_store(ce + b, l - target_logit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = 0;
+    if (loss) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (mine == (unsigned int)(B - 1)) s_last = 1;
+    }
+  }
+  __syncthreads();
+  if (s_last) {
+    float a = 0.f;
+    for (int i = tid; i < n_l2; i += 256) a += l2_partial[i];
+    const float l2 = 0.5f * block_reduce_sum(a, red);
+    a = 0.f;
+    for (int i = tid; i < B; i += 256) a += __hip_atomic_load(ce + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float ces = block_reduce_sum(a, red);
+    if (tid == 0) {
+      loss[0] = reg * l2 + ce_scale * ces;
+      loss[1] = l2;
+      loss[2] = ces / (float)B;
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ top-K
 // Radix select on an order-preserving integer image of the float (3 digit
 // passes of 11/11/10 bits), then an index-ordered sweep that keeps everything
@@ -332,6 +407,24 @@ extern "C" int mtam_loss_reduce(const float *l2_partial, int n_l2, const float *
                      n_l2, ce, B, reg, ce_scale, loss);
   MTAM_CHECK_LAUNCH("loss_reduce");
   return MTAM_OK;
+}
+
+extern "C" int mtam_softmax_ce_loss(const float *logits, int ld, const int32_t *target, int B, int V,
+                                    float grad_scale, float *lse, float *ce, float *d_logits, float *partial,
+                                    const float *l2_partial, int n_l2, float reg, float ce_scale, float *loss,
+                                    void *stream) {
+  MTAM_CHECK_ARG(logits && target && lse && ce && partial && (l2_partial || !loss), "softmax_ce_loss: null argument");
+  MTAM_CHECK_ARG(B > 0 && B <= 65535 && V > 0 && ld >= V && n_l2 >= 0, "softmax_ce_loss: bad shape");
+  if (V <= 256 * CE_ROW_MAX) {
+    hipLaunchKernelGGL(ce_row_loss_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), logits, ld,
+                       target, B, V, grad_scale, lse, ce, d_logits, reinterpret_cast<unsigned int *>(partial),
+                       l2_partial, n_l2, reg, ce_scale, loss);
+    MTAM_CHECK_LAUNCH("softmax_ce_loss");
+    return MTAM_OK;
+  }
+  int rc = mtam_softmax_ce(logits, ld, target, B, V, grad_scale, lse, ce, d_logits, partial + 4, stream);
+  if (rc || !loss) return rc;
+  return mtam_loss_reduce(l2_partial, n_l2, ce, B, reg, ce_scale, loss, stream);
 }
 
 extern "C" int mtam_topk(const float *scores, int ld, int rows, int V, int k, int32_t *idx_out,

@@ -166,6 +166,15 @@ def loss_reduce(l2_partial, n_l2, ce, B, reg, ce_scale, loss):
                                     _p(loss), _stream()), "mtam_loss_reduce")
 
 
+def softmax_ce_loss(logits, ld, target, B, V, grad_scale, lse, ce, d_logits, partial, l2_partial, n_l2, reg,
+                    ce_scale, loss):
+    lib = _lib.load()
+    rc = lib.mtam_softmax_ce_loss(_p(logits), ld, _pi(target), B, V, float(grad_scale), _p(lse), _p(ce),
+                                  _p(d_logits), _p(partial), _p(l2_partial), n_l2, float(reg), float(ce_scale),
+                                  _p(loss), _stream())     # loss may be None
+    _lib.check(rc, "mtam_softmax_ce_loss")
+
+
 def topk(scores, ld, rows, V, k, idx_out, val_out=None):
     lib = _lib.load()
     _lib.check(lib.mtam_topk(_p(scores), ld, rows, V, k, _pi(idx_out), _p(val_out), _stream()), "mtam_topk")
@@ -184,6 +193,15 @@ def clip_scale(partials, n_partials, clip_norm, scale, lr=None, adam_state=None)
     lib = _lib.load()
     _lib.check(lib.mtam_clip_scale(_p(partials), n_partials, float(clip_norm), _p(scale), _p(lr),
                                    _p(adam_state), _stream()), "mtam_clip_scale")
+
+
+def sqnorm_clip_scale(g, n, partials, offset, n_total, clip_norm, scale, lr, adam_state, ticket,
+                      l2_partial=None, n_l2=0, ce=None, B=0, reg=0.0, ce_scale=0.0, loss=None):
+    lib = _lib.load()
+    rc = lib.mtam_sqnorm_clip_scale(_p(g), n, _p(partials), offset, n_total, float(clip_norm), _p(scale), _p(lr),
+                                    _p(adam_state), _pi(ticket), _p(l2_partial), n_l2, _p(ce), B, float(reg),
+                                    float(ce_scale), _p(loss), _stream())
+    _lib.check(rc, "mtam_sqnorm_clip_scale")
 
 
 def adam_block():

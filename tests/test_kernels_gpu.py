@@ -437,6 +437,32 @@ def test_softmax_ce(ops, B, V):
     assert np.allclose(loss.cpu().numpy(), [5e-5 * l2 + ces / B, l2, ces / B], rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,V", [(3, 10), (128, 3709), (7, 16384), (5, 20000)])
+def test_softmax_ce_loss_fused(ops, B, V):
+    """One-launch form (V <= 16384) and the multi-launch fallback give the same numbers, call after call
+    (the arrival ticket resets itself)."""
+    rng = np.random.default_rng(V + B)
+    logits = (rng.standard_normal((B, V)) * 3).astype(np.float32)
+    target = rng.integers(0, V, size=B).astype(np.int32)
+    l2p = rng.uniform(0, 1, 77).astype(np.float32)
+    l64 = logits.astype(np.float64)
+    m = l64.max(1, keepdims=True)
+    ref_lse = m[:, 0] + np.log(np.exp(l64 - m).sum(1))
+    ref_ce = ref_lse - l64[np.arange(B), target]
+    g = np.exp(l64 - ref_lse[:, None])
+    g[np.arange(B), target] -= 1
+    part = torch.zeros(ops.softmax_ce_partials(B, V) + 4, device="cuda")
+    lse, ce, loss = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda"), torch.zeros(3, device="cuda")
+    for _ in range(3):
+        lg = dev(logits)
+        ops.softmax_ce_loss(lg, V, dev(target), B, V, 1.0 / B, lse, ce, lg, part, dev(l2p), 77, 5e-5, 1.0 / B, loss)
+        assert rel_err(lse.cpu().numpy(), ref_lse) < 1e-6
+        assert rel_err(ce.cpu().numpy(), ref_ce) < 1e-6
+        assert np.abs(lg.cpu().numpy() - g / B).max() < 1e-5 / B
+        l2 = 0.5 * float(l2p.astype(np.float64).sum())
+        assert np.allclose(loss.cpu().numpy(), [5e-5 * l2 + ref_ce.mean(), l2, ref_ce.mean()], rtol=1e-5)
+
+
 # ------------------------------------------------------------------ top-K
 @pytest.mark.parametrize("rows,V,k", [(4, 10, 50), (7, 3709, 50), (3, 70000, 50), (5, 300, 1), (2, 64, 64)])
 def test_topk_bit_exact(ops, rows, V, k):
@@ -493,6 +519,17 @@ def test_clip_and_adam(ops):
         assert abs(st[0] - want) <= 1e-6 * want
         b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
         assert st[4] == b1p and st[5] == b2p
+    # fused sqnorm + clip + Adam bookkeeping: same result as the two separate launches, repeatably
+    part2 = torch.zeros(nb + 2, device="cuda")
+    part2[nb] = 2.5
+    part2[nb + 1] = 0.5
+    scale2 = torch.zeros(2, device="cuda")
+    ticket = torch.zeros(4, dtype=torch.int32, device="cuda")
+    state2 = dev(np.array([0, 0.9, 0.999, 1e-8, 0.9, 0.999, 0, 0], np.float32))
+    for rep in range(3):
+        ops.sqnorm_clip_scale(dev(g), n, part2, 0, nb + 2, 1.0, scale2, lr, state2, ticket)
+        assert abs(float(scale2[1]) - norm) / norm < 1e-6 and int(ticket[0]) == 0
+    assert np.allclose(state2.cpu().numpy(), state.cpu().numpy(), rtol=1e-6)
     sc = np.float32(scale[0].item())
     lr_t, b1, b2, eps = np.float32(1e-3), np.float32(0.9), np.float32(0.999), np.float32(1e-8)
     hyper = dev(np.array([lr_t, b1, b2, eps], np.float32))
