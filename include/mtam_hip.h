@@ -77,6 +77,16 @@ int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
                   const float *aux_in, float *aux_out, int ld_aux,
                   int split_k, void *stream);
 
+/* Batched GEMM: batch0 x batch1 independent problems of one shape in one launch; problem (z0, z1)
+ * uses A + z0*sA0 + z1*sA1 (element offsets; same for B and C).  The L x L products of the
+ * self-attention encoder: Q_h K_h^T, (q Wt) k^T, W V and their gradients
+ * (Model/Modules/time_aware_attention.py:320-321,380,443).  Epilogue STORE or ACCUM. */
+int mtam_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K,
+                          const float *A, int lda, long sA0, long sA1,
+                          const float *B, int ldb, long sB0, long sB1,
+                          float *C, int ldc, long sC0, long sC1,
+                          int batch0, int batch1, int epilogue, void *stream);
+
 /* Grouped weight-gradient GEMMs: n <= MTAM_MAX_GROUP independent problems
  * C[M,N] += A^T B with A [K,M] (lda), B [K,N] (ldb), split-K slices added by
  * atomics, all in ONE launch (the dW of every dense layer after backward;
@@ -211,15 +221,46 @@ int mtam_ta_attn_decode_bwd(const float *d_out, const float *dec_in, const float
                             float *d_tparams_partial, float *d_ln_partial, void *stream);
 
 /* ------------------------------------------------------------- layer norm
- * tf.contrib.layers.layer_norm (Model/Modules/net_utils.py:229-232,
- * Model/MTAMRec_model.py:91): y = x*inv + (beta - mean*inv), inv = rsqrt(var+eps)*gamma.
- *   save [rows, D + 1]: xhat | rstd, or NULL
+ * y = LN(x [+ resid]) over the last dimension (D = 128), two forms:
+ *   form 0  tf.contrib.layers.layer_norm (Model/Modules/net_utils.py:229-232,
+ *           Model/MTAMRec_model.py:91): x*inv + (beta - mean*inv), inv = rsqrt(var+eps)*gamma
+ *   form 1  Time_Aware_Attention.normalize (Model/Modules/time_aware_attention.py:7-34,451-454):
+ *           gamma*(x-mean)/sqrt(var+eps) + beta, with the residual `resid` added first
+ *   save [rows, D + 1]: xhat | rstd, or NULL.  The backward is the same for both forms; its d_x is
+ *   also the gradient of `resid`.
  */
-int mtam_layer_norm_fwd(const float *x, const float *beta, const float *gamma, float eps,
-                        int rows, float *y, float *save, void *stream);
+int mtam_layer_norm_fwd(const float *x, const float *resid, const float *beta, const float *gamma,
+                        float eps, int form, int rows, float *y, float *save, void *stream);
 /*   d_bg [2, D]: atomicAdd of d_beta | d_gamma */
 int mtam_layer_norm_bwd(const float *d_y, const float *gamma, const float *save, int rows,
                         float *d_x, float *d_bg, void *stream);
+
+/* --------------------------------- time-aware attention, T_q = T_k = L (encoder)
+ * Row-wise part of one self_attention block (Model/Modules/time_aware_attention.py:320-431,
+ * Model/PISTRec_model.py:38-53); the L x L products run through mtam_gemm_f32_batched.
+ *   s_raw [B,H,L,L] = Q_h K_h^T;  a [B,L,L]: in (q Wt) k^T, out tanh of it;  t [B,L] times
+ *   tparams [5,L,L]: _time_input_w1, _time_input_b1, time_output_w1, time_output_w2, time_output_b
+ *   w [B,H,L,L] = softmax_j(mask(s_raw * sigmoid(gate) / sqrt(d))) with query rows >= seq_len zeroed
+ *   dk, sg [B,L,L]: saved tanh(decay) and sigmoid(gate)
+ * Backward: dw in = d loss / d w, out = d loss / d s_raw;  d_a = d loss / d ((q Wt) k^T);
+ *   g_tparams [5,L,L] += gradients (atomics over the batch).
+ */
+int mtam_ta_selfattn_gate_softmax_fwd(const float *s_raw, float *a, const float *t, const int32_t *seq_len,
+                                      const float *tparams, int B, int L, int H, float *w, float *dk,
+                                      float *sg, void *stream);
+int mtam_ta_selfattn_gate_softmax_bwd(float *dw, const float *w, const float *s_raw, const float *a,
+                                      const float *dk, const float *sg, const float *t,
+                                      const int32_t *seq_len, const float *tparams, int B, int L, int H,
+                                      float *d_a, float *g_tparams, void *stream);
+
+/* gather_indexes(seq [B*L, D], seq_len + offset) -> out [B, D] (Model/Modules/net_utils.py:82-92) and its
+ * gradient: d_src [B*L, D] = 0 except row seq_len[b] + offset of sample b = d_out[b]. */
+int mtam_seq_row_gather(const float *src, const int32_t *seq_len, int offset, int B, int L, float *out,
+                        void *stream);
+int mtam_seq_row_scatter(const float *d_out, const int32_t *seq_len, int offset, int B, int L, float *d_src,
+                         void *stream);
+/* d[i] = y[i] > 0 ? d[i] : 0 (gradient through tf.nn.relu); n a multiple of 4 */
+int mtam_relu_bwd_inplace(float *d, const float *y, size_t n, void *stream);
 
 /* --------------------------------------------------- full-catalog softmax CE
  * log_softmax + one-hot cross entropy over logits [B, V]

@@ -110,13 +110,16 @@ class _Batch(object):
 class TimeAwarePath(object):
     """Owns parameters, optimizer state and the kernel sequence for MTAM."""
 
+    MODEL = "MTAM"
+    BATCH_CLASS = None       # set below
+
     def __init__(self, tables, dense_tf, L, num_heads, num_blocks, regulation_rate, max_gradient_norm,
                  tf_compat_global_norm=True, device="cuda:0"):
         self.device = dev = torch.device(device)
         self.L, self.H, self.NB = L, num_heads, num_blocks
         self.reg, self.clip = float(regulation_rate), float(max_gradient_norm)
         self.tf_compat = bool(tf_compat_global_norm)
-        self.layout = DenseLayout("MTAM", D, L, num_blocks)
+        self.layout = DenseLayout(self.MODEL, D, L, num_blocks)
         for k, v in tables.items():
             if v.shape[1] != D:
                 raise ValueError("this build supports num_units == %d only (table %s has %d)" % (D, k, v.shape[1]))
@@ -171,7 +174,7 @@ class TimeAwarePath(object):
 
     def batch(self, B):
         if B not in self._batches:
-            self._batches[B] = _Batch(self, B)
+            self._batches[B] = (self.BATCH_CLASS or _Batch)(self, B)
         return self._batches[B]
 
     def fill_host(self, bt, feed, lr=None):

@@ -20,6 +20,9 @@ SIGNATURES = {
     "mtam_arch": (ctypes.c_char_p, []),
     "mtam_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int,
                               P, P, P, c_int, c_int, P]),
+    "mtam_gemm_f32_batched": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, ctypes.c_long, ctypes.c_long,
+                                      P, c_int, ctypes.c_long, ctypes.c_long, P, c_int, ctypes.c_long,
+                                      ctypes.c_long, c_int, c_int, c_int, P]),
     "mtam_colsum_atomic": (c_int, [P, c_int, c_int, c_int, P, P]),
     "mtam_emb_gather_partials": (c_int, [c_int, c_int]),
     "mtam_emb_gather_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
@@ -34,7 +37,12 @@ SIGNATURES = {
                                         c_int, c_int, c_int, P, P, P]),
     "mtam_ta_attn_decode_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P,
                                         c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
-    "mtam_layer_norm_fwd": (c_int, [P, P, P, c_float, c_int, P, P, P]),
+    "mtam_layer_norm_fwd": (c_int, [P, P, P, P, c_float, c_int, c_int, P, P, P]),
+    "mtam_ta_selfattn_gate_softmax_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P]),
+    "mtam_ta_selfattn_gate_softmax_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P]),
+    "mtam_seq_row_gather": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "mtam_seq_row_scatter": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "mtam_relu_bwd_inplace": (c_int, [P, P, c_size_t, P]),
     "mtam_layer_norm_bwd": (c_int, [P, P, P, c_int, P, P, P]),
     "mtam_softmax_ce_partials": (c_int, [c_int, c_int]),
     "mtam_softmax_ce": (c_int, [P, c_int, P, c_int, c_int, c_float, P, P, P, P, P]),

@@ -30,6 +30,9 @@ struct GemmArgs {
   int k_chunk;
   int vecA, vecB;
   int tiles_n;
+  // batched form: grid.y = batch index z -> (z / heads, z % heads), element offsets per operand
+  int heads;
+  long sA0, sA1, sB0, sB1, sC0, sC1;
 };
 
 // Source laid out src[r][k] (k contiguous): tile of 64 rows x 32 k.
@@ -228,6 +231,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float As[2 * TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float Bs[2 * TILE_FLOATS];
   // 1-D tile index (grid.y is capped at 65535; V/64 is not), split-K slice on grid.y
+  if (p.heads > 0) {                       // batched: grid.y is the batch index, no split-K
+    GemmArgs q = p;
+    const long z0 = blockIdx.y / p.heads, z1 = blockIdx.y % p.heads;
+    q.A += z0 * p.sA0 + z1 * p.sA1;
+    q.B += z0 * p.sB0 + z1 * p.sB1;
+    q.C += z0 * p.sC0 + z1 * p.sC1;
+    gemm_tile<TA, TB, EPI>(q, As, Bs, blockIdx.x, 0);
+    return;
+  }
   gemm_tile<TA, TB, EPI>(p, As, Bs, blockIdx.x, blockIdx.y);
 }
 
@@ -296,6 +308,8 @@ extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, cons
   a.vecA = (lda % 4 == 0) && mtam_aligned16(A);
   a.vecB = (ldb % 4 == 0) && mtam_aligned16(B);
   a.tiles_n = (int)gx;
+  a.heads = 0;
+  a.sA0 = a.sA1 = a.sB0 = a.sB1 = a.sC0 = a.sC1 = 0;
   dim3 grid((unsigned)(gx * gy), (unsigned)split_k, 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (trans_a) {
@@ -309,6 +323,39 @@ extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, cons
   return MTAM_OK;
 }
 
+
+extern "C" int mtam_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                                     long sA0, long sA1, const float *B, int ldb, long sB0, long sB1, float *C,
+                                     int ldc, long sC0, long sC1, int batch0, int batch1, int epilogue,
+                                     void *stream) {
+  MTAM_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch0 > 0 && batch1 > 0, "gemm_batched: bad sizes");
+  MTAM_CHECK_ARG(A && B && C, "gemm_batched: null operand");
+  MTAM_CHECK_ARG(epilogue == MTAM_EPI_STORE || epilogue == MTAM_EPI_ACCUM, "gemm_batched: STORE or ACCUM only");
+  MTAM_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "gemm_batched: bad leading dimension");
+  MTAM_CHECK_ARG((long)batch0 * batch1 <= 65535, "gemm_batched: at most 65535 problems per launch");
+  const long gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = nullptr; a.aux_in = nullptr; a.aux_out = nullptr;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ld_aux = 0;
+  a.k_chunk = ((K + BK - 1) / BK) * BK;
+  // vector loads need every problem's base 16-byte aligned
+  a.vecA = (lda % 4 == 0) && mtam_aligned16(A) && sA0 % 4 == 0 && sA1 % 4 == 0;
+  a.vecB = (ldb % 4 == 0) && mtam_aligned16(B) && sB0 % 4 == 0 && sB1 % 4 == 0;
+  a.tiles_n = (int)gx;
+  a.heads = batch1;
+  a.sA0 = sA0; a.sA1 = sA1; a.sB0 = sB0; a.sB1 = sB1; a.sC0 = sC0; a.sC1 = sC1;
+  dim3 grid((unsigned)(gx * gy), (unsigned)(batch0 * batch1), 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (trans_a) {
+    if (trans_b) launch_epi<true, true>(epilogue, grid, s, a);
+    else         launch_epi<true, false>(epilogue, grid, s, a);
+  } else {
+    if (trans_b) launch_epi<false, true>(epilogue, grid, s, a);
+    else         launch_epi<false, false>(epilogue, grid, s, a);
+  }
+  MTAM_CHECK_LAUNCH("gemm_batched");
+  return MTAM_OK;
+}
 
 extern "C" int mtam_gemm_tn_atomic_grouped(int n, const MtamGemmDesc *d, void *stream) {
   MTAM_CHECK_ARG(n >= 1 && n <= MTAM_MAX_GROUP && d, "gemm_grouped: 1 <= n <= %d problems", MTAM_MAX_GROUP);
@@ -330,6 +377,8 @@ extern "C" int mtam_gemm_tn_atomic_grouped(int n, const MtamGemmDesc *d, void *s
     a.vecA = (q.lda % 4 == 0) && mtam_aligned16(q.A);
     a.vecB = (q.ldb % 4 == 0) && mtam_aligned16(q.B);
     a.tiles_n = (q.N + BN - 1) / BN;
+    a.heads = 0;
+    a.sA0 = a.sA1 = a.sB0 = a.sB1 = a.sC0 = a.sC1 = 0;
     ga.first[i] = blocks;
     blocks += a.tiles_n * ((q.M + BM - 1) / BM) * split;
   }

@@ -12,20 +12,34 @@ constexpr int D = MTAM_D;
 constexpr int CE_CHUNK = 4096;   // logits per workgroup in the softmax passes
 
 // ------------------------------------------------------------- layer norm
-__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float *__restrict__ x, const float *beta,
-                                                             const float *gamma, float eps, int rows,
+__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float *__restrict__ x,
+                                                             const float *__restrict__ resid, const float *beta,
+                                                             const float *gamma, float eps, int form, int rows,
                                                              float *__restrict__ y, float *__restrict__ save) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float x0 = x[(size_t)row * D + lane], x1 = x[(size_t)row * D + 64 + lane];
+  float x0 = x[(size_t)row * D + lane], x1 = x[(size_t)row * D + 64 + lane];
+  if (resid) {
+    x0 += resid[(size_t)row * D + lane];
+    x1 += resid[(size_t)row * D + 64 + lane];
+  }
   const float mean = wave_sum(x0 + x1) / (float)D;
   const float d0 = x0 - mean, d1 = x1 - mean;
   const float var = wave_sum(d0 * d0 + d1 * d1) / (float)D;
-  const float rstd = 1.0f / sqrtf(var + eps);
-  // nn.batch_normalization form: x * inv + (beta - mean * inv)
-  const float i0 = rstd * gamma[lane], i1 = rstd * gamma[64 + lane];
-  y[(size_t)row * D + lane] = x0 * i0 + (beta[lane] - mean * i0);
-  y[(size_t)row * D + 64 + lane] = x1 * i1 + (beta[64 + lane] - mean * i1);
+  float rstd;
+  if (form == 0) {
+    // tf.contrib.layers.layer_norm via nn.batch_normalization: x * inv + (beta - mean * inv)
+    rstd = 1.0f / sqrtf(var + eps);
+    const float i0 = rstd * gamma[lane], i1 = rstd * gamma[64 + lane];
+    y[(size_t)row * D + lane] = x0 * i0 + (beta[lane] - mean * i0);
+    y[(size_t)row * D + 64 + lane] = x1 * i1 + (beta[64 + lane] - mean * i1);
+  } else {
+    // Time_Aware_Attention.normalize: gamma * (x - mean) / sqrt(var + eps) + beta
+    const float sd = sqrtf(var + eps);
+    rstd = 1.0f / sd;
+    y[(size_t)row * D + lane] = gamma[lane] * (d0 / sd) + beta[lane];
+    y[(size_t)row * D + 64 + lane] = gamma[64 + lane] * (d1 / sd) + beta[64 + lane];
+  }
   if (save) {
     save[(size_t)row * (D + 1) + lane] = d0 * rstd;
     save[(size_t)row * (D + 1) + 64 + lane] = d1 * rstd;
@@ -362,11 +376,11 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ sco
 
 }  // namespace
 
-extern "C" int mtam_layer_norm_fwd(const float *x, const float *beta, const float *gamma, float eps,
-                                   int rows, float *y, float *save, void *stream) {
-  MTAM_CHECK_ARG(x && beta && gamma && y && rows > 0, "layer_norm_fwd: bad arguments");
+extern "C" int mtam_layer_norm_fwd(const float *x, const float *resid, const float *beta, const float *gamma,
+                                   float eps, int form, int rows, float *y, float *save, void *stream) {
+  MTAM_CHECK_ARG(x && beta && gamma && y && rows > 0 && (form == 0 || form == 1), "layer_norm_fwd: bad arguments");
   hipLaunchKernelGGL(layer_norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, beta, gamma, eps, rows, y, save);
+                     static_cast<hipStream_t>(stream), x, resid, beta, gamma, eps, form, rows, y, save);
   MTAM_CHECK_LAUNCH("layer_norm_fwd");
   return MTAM_OK;
 }

@@ -59,6 +59,17 @@ def gemm(a, b, c, trans_a=False, trans_b=False, epilogue=EPI_STORE, bias=None, a
     _lib.check(rc, "mtam_gemm_f32")
 
 
+def gemm_batched(a, b, c, M, N, K, lda, sa, ldb, sb, ldc, sc, batch, trans_a=False, trans_b=False,
+                 epilogue=EPI_STORE):
+    """batch = (batch0, batch1); sa/sb/sc = (stride over batch0, stride over batch1) in elements.
+    a, b, c: base tensors (any shape, contiguous storage)."""
+    lib = _lib.load()
+    rc = lib.mtam_gemm_f32_batched(int(trans_a), int(trans_b), M, N, K, _p(a), lda, sa[0], sa[1], _p(b), ldb,
+                                   sb[0], sb[1], _p(c), ldc, sc[0], sc[1], batch[0], batch[1], epilogue,
+                                   _stream())
+    _lib.check(rc, "mtam_gemm_f32_batched")
+
+
 def colsum_atomic(x, out, rows=None, cols=None, ld=None):
     lib = _lib.load()
     rows = x.shape[0] if rows is None else rows
@@ -137,10 +148,41 @@ def ta_attn_decode_bwd(d_out, dec_in, x, kv, ld_kv, k_off, v_off, t_query, t_key
     _lib.check(rc, "mtam_ta_attn_decode_bwd")
 
 
-def layer_norm_fwd(x, beta, gamma, eps, rows, y, save):
+def layer_norm_fwd(x, beta, gamma, eps, rows, y, save, resid=None, form=0):
     lib = _lib.load()
-    _lib.check(lib.mtam_layer_norm_fwd(_p(x), _p(beta), _p(gamma), float(eps), rows, _p(y), _p(save),
-                                       _stream()), "mtam_layer_norm_fwd")
+    _lib.check(lib.mtam_layer_norm_fwd(_p(x), _p(resid), _p(beta), _p(gamma), float(eps), form, rows, _p(y),
+                                       _p(save), _stream()), "mtam_layer_norm_fwd")
+
+
+def ta_selfattn_gate_softmax_fwd(s_raw, a, t, seq_len, tparams, B, L, H, w, dk, sg):
+    lib = _lib.load()
+    _lib.check(lib.mtam_ta_selfattn_gate_softmax_fwd(_p(s_raw), _p(a), _p(t), _pi(seq_len), _p(tparams), B, L, H,
+                                                     _p(w), _p(dk), _p(sg), _stream()),
+               "mtam_ta_selfattn_gate_softmax_fwd")
+
+
+def ta_selfattn_gate_softmax_bwd(dw, w, s_raw, a, dk, sg, t, seq_len, tparams, B, L, H, d_a, g_tparams):
+    lib = _lib.load()
+    _lib.check(lib.mtam_ta_selfattn_gate_softmax_bwd(_p(dw), _p(w), _p(s_raw), _p(a), _p(dk), _p(sg), _p(t),
+                                                     _pi(seq_len), _p(tparams), B, L, H, _p(d_a), _p(g_tparams),
+                                                     _stream()), "mtam_ta_selfattn_gate_softmax_bwd")
+
+
+def seq_row_gather(src, seq_len, offset, B, L, out):
+    lib = _lib.load()
+    _lib.check(lib.mtam_seq_row_gather(_p(src), _pi(seq_len), offset, B, L, _p(out), _stream()),
+               "mtam_seq_row_gather")
+
+
+def seq_row_scatter(d_out, seq_len, offset, B, L, d_src):
+    lib = _lib.load()
+    _lib.check(lib.mtam_seq_row_scatter(_p(d_out), _pi(seq_len), offset, B, L, _p(d_src), _stream()),
+               "mtam_seq_row_scatter")
+
+
+def relu_bwd_inplace(d, y, n):
+    lib = _lib.load()
+    _lib.check(lib.mtam_relu_bwd_inplace(_p(d), _p(y), n, _stream()), "mtam_relu_bwd_inplace")
 
 
 def layer_norm_bwd(d_y, gamma, save, rows, d_x, d_bg):

@@ -100,9 +100,14 @@ class Train_main_process(object):
         self.sess = Session(self.device)
         if self.FLAGS.experiment_type == "MTAM":
             self.model = MTAM(self.FLAGS, self.emb, self.sess)
+        elif self.FLAGS.experiment_type in ("Time_Aware_Self_Attention_Model", "PISTRec"):
+            # train_process.py:209-210 dispatches Model/attention_baseline_models.py:47-65, the twin of
+            # PISTRec's Time_Aware_self_Attention_model (same graph; only the user L2 term differs)
+            from .Model.PISTRec_model import Time_Aware_self_Attention_model
+            self.model = Time_Aware_self_Attention_model(self.FLAGS, self.emb, self.sess)
         else:
-            raise NotImplementedError("experiment_type %r has no HIP path yet (MTAM only)"
-                                      % self.FLAGS.experiment_type)
+            raise NotImplementedError("experiment_type %r has no HIP path (MTAM and the time-aware "
+                                      "self-attention model only)" % self.FLAGS.experiment_type)
         return self.model
 
     def eval_topk(self):

@@ -9,13 +9,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "mtam_*.npz"))))
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))))
 def test_hip_matches_golden(hip_lib, tmp_path, path):
     from mtamrecommender_amd.config.model_parameter import model_parameter
     from mtamrecommender_amd.Embedding.Behavior_embedding_time_aware_attention import \
         Behavior_embedding_time_aware_attention
     from mtamrecommender_amd.Model.base_model import Session
     from mtamrecommender_amd.Model.MTAMRec_model import MTAM
+    from mtamrecommender_amd.Model.PISTRec_model import Time_Aware_self_Attention_model
     from tests.golden.make_golden import CASES, make_case
     name = os.path.splitext(os.path.basename(path))[0]
     model_name, B, L, D, NB, H, items, cats, users, seed = CASES[name]
@@ -25,7 +26,7 @@ def test_hip_matches_golden(hip_lib, tmp_path, path):
     FLAGS.num_blocks, FLAGS.num_heads, FLAGS.length_of_user_history = NB, H, L
     FLAGS.checkpoint_path_dir = str(tmp_path)
     emb = Behavior_embedding_time_aware_attention(True, users, items, cats, L)
-    model = MTAM(FLAGS, emb, Session("cuda:0"))
+    model = (MTAM if model_name == "MTAM" else Time_Aware_self_Attention_model)(FLAGS, emb, Session("cuda:0"))
     model.use_graph = False
     model.set_variables(arrays)
     p = model.path

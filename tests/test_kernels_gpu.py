@@ -119,6 +119,35 @@ def test_gemm_submatrix_views(ops):
     assert rel_err(C.cpu().numpy(), ref) < 2e-6
 
 
+def test_gemm_batched(ops):
+    """(sample, head) batches over sub-matrices of packed buffers, as the self-attention encoder uses them."""
+    rng = np.random.default_rng(21)
+    Bn, H, L, d = 3, 4, 37, 32
+    Dm = H * d
+    qkv = rng.standard_normal((Bn * L, 3 * Dm)).astype(np.float32)
+    out = torch.full((Bn, H, L, L), 9.0, device="cuda")
+    qd = dev(qkv)
+    ops.gemm_batched(qd, qd.view(-1)[Dm:], out, L, L, d, 3 * Dm, (L * 3 * Dm, d), 3 * Dm, (L * 3 * Dm, d), L,
+                     (H * L * L, L * L), (Bn, H), trans_b=True)
+    q3 = qkv.reshape(Bn, L, 3 * Dm).astype(np.float64)
+    ref = np.einsum("bihc,bjhc->bhij", q3[:, :, :Dm].reshape(Bn, L, H, d), q3[:, :, Dm:2 * Dm].reshape(Bn, L, H, d))
+    assert rel_err(out.cpu().numpy(), ref) < 2e-6
+    # W V with accumulate into a strided output, and the transposed-A form
+    w = rng.standard_normal((Bn, H, L, L)).astype(np.float32)
+    o0 = rng.standard_normal((Bn * L, Dm)).astype(np.float32)
+    o = dev(o0).clone()
+    ops.gemm_batched(dev(w), qd.view(-1)[2 * Dm:], o, L, d, L, L, (H * L * L, L * L), 3 * Dm, (L * 3 * Dm, d), Dm,
+                     (L * Dm, d), (Bn, H), epilogue=ops.EPI_ACCUM)
+    v = q3[:, :, 2 * Dm:].reshape(Bn, L, H, d)
+    ref = o0.reshape(Bn, L, H, d) + np.einsum("bhij,bjhc->bihc", w.astype(np.float64), v)
+    assert rel_err(o.cpu().numpy().reshape(Bn, L, H, d), ref) < 2e-6
+    o2 = torch.zeros((Bn * L, Dm), device="cuda")
+    ops.gemm_batched(dev(w), qd.view(-1)[2 * Dm:], o2, L, d, L, L, (H * L * L, L * L), 3 * Dm, (L * 3 * Dm, d), Dm,
+                     (L * Dm, d), (Bn, H), trans_a=True)
+    ref = np.einsum("bhji,bjhc->bihc", w.astype(np.float64), v)
+    assert rel_err(o2.cpu().numpy().reshape(Bn, L, H, d), ref) < 2e-6
+
+
 def test_gemm_rejects_bad_arguments(ops):
     from mtamrecommender_amd._lib import MtamHipError
     a = torch.zeros((8, 8), device="cuda")
@@ -384,6 +413,49 @@ def test_ta_attn_decode_fwd_bwd(ops, B, L, H):
 
 
 # ------------------------------------------------------------ layer norm
+def test_normalize_with_residual(ops):
+    import oracle.mtam_oracle as O
+    rng = np.random.default_rng(10)
+    rows = 41
+    x = rng.standard_normal((rows, D)).astype(np.float32)
+    res = rng.standard_normal((rows, D)).astype(np.float32)
+    beta = rng.standard_normal(D).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, D).astype(np.float32)
+    y = torch.zeros((rows, D), device="cuda")
+    save = torch.zeros((rows, D + 1), device="cuda")
+    ops.layer_norm_fwd(dev(x), dev(beta), dev(gamma), 1e-8, rows, y, save, resid=dev(res), form=1)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = O.normalize(xt + torch.tensor(res, dtype=torch.float64), torch.tensor(beta, dtype=torch.float64),
+                      torch.tensor(gamma, dtype=torch.float64))
+    assert rel_err(y.cpu().numpy(), ref.detach().numpy()) < 2e-6
+    dy = rng.standard_normal((rows, D)).astype(np.float32)
+    (ref * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    dx = torch.zeros((rows, D), device="cuda")
+    dbg = torch.zeros((2, D), device="cuda")
+    ops.layer_norm_bwd(dev(dy), dev(gamma), save, rows, dx, dbg)
+    assert rel_err(dx.cpu().numpy(), xt.grad.numpy()) < 1e-5
+
+
+def test_seq_row_gather_scatter_and_relu_bwd(ops):
+    rng = np.random.default_rng(12)
+    B, L = 7, 9
+    src = rng.standard_normal((B * L, D)).astype(np.float32)
+    sl = rng.integers(2, L + 1, size=B).astype(np.int32)
+    out = torch.zeros((B, D), device="cuda")
+    ops.seq_row_gather(dev(src), dev(sl), -1, B, L, out)
+    assert np.array_equal(out.cpu().numpy(), src.reshape(B, L, D)[np.arange(B), sl - 1])
+    d_src = torch.full((B * L, D), 5.0, device="cuda")
+    ops.seq_row_scatter(out, dev(sl), -1, B, L, d_src)
+    want = np.zeros((B, L, D), np.float32)
+    want[np.arange(B), sl - 1] = out.cpu().numpy()
+    assert np.array_equal(d_src.cpu().numpy().reshape(B, L, D), want)
+    dd = rng.standard_normal((B * L, D)).astype(np.float32)
+    yy = rng.standard_normal((B * L, D)).astype(np.float32)
+    dt = dev(dd).clone()
+    ops.relu_bwd_inplace(dt, dev(yy), dt.numel())
+    assert np.array_equal(dt.cpu().numpy(), np.where(yy > 0, dd, 0))
+
+
 def test_layer_norm(ops):
     import oracle.mtam_oracle as O
     rng = np.random.default_rng(9)
@@ -393,7 +465,7 @@ def test_layer_norm(ops):
     gamma = rng.uniform(0.5, 1.5, D).astype(np.float32)
     y = torch.zeros((rows, D), device="cuda")
     save = torch.zeros((rows, D + 1), device="cuda")
-    ops.layer_norm_fwd(dev(x), dev(beta), dev(gamma), 1e-12, rows, y, save)
+    ops.layer_norm_fwd(dev(x), dev(beta), dev(gamma), 1e-12, rows, y, save)   # contrib form, no residual
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     bt = torch.tensor(beta, dtype=torch.float64, requires_grad=True)
     gt = torch.tensor(gamma, dtype=torch.float64, requires_grad=True)

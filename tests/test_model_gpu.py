@@ -19,11 +19,12 @@ LOGIT_TOL = 5e-5      # relative to max |logit|
 GRAD_TOL = 5e-4       # relative max-norm per gradient tensor (fp32 kernels vs fp64 oracle)
 
 
-def build(tmp_path, B, L, NB, H, items=300, cats=17, users=40, seed=5, id_dist="zipf"):
+def build(tmp_path, B, L, NB, H, items=300, cats=17, users=40, seed=5, id_dist="zipf", model_name="MTAM"):
     from mtamrecommender_amd.config.model_parameter import model_parameter
     from mtamrecommender_amd.Embedding.Behavior_embedding_time_aware_attention import \
         Behavior_embedding_time_aware_attention
     from mtamrecommender_amd.Model.MTAMRec_model import MTAM
+    from mtamrecommender_amd.Model.PISTRec_model import Time_Aware_self_Attention_model
     from mtamrecommender_amd.Model.base_model import Session
     from mtamrecommender_amd.data.synthetic import SyntheticCatalog, make_records
     FLAGS = model_parameter().get_parameter("MTAMb1_movielen").FLAGS
@@ -31,7 +32,8 @@ def build(tmp_path, B, L, NB, H, items=300, cats=17, users=40, seed=5, id_dist="
     FLAGS.checkpoint_path_dir = str(tmp_path)
     cat = SyntheticCatalog(items, cats, users, seed=seed)
     emb = Behavior_embedding_time_aware_attention(True, users, items, cats, L, seed=seed)
-    model = MTAM(FLAGS, emb, Session("cuda:0"))
+    cls = MTAM if model_name == "MTAM" else Time_Aware_self_Attention_model
+    model = cls(FLAGS, emb, Session("cuda:0"))
     # make every bias / scale non-trivial so that all gradient paths are exercised
     rng = np.random.default_rng(seed)
     arrays = model.get_variables()
@@ -189,3 +191,56 @@ def test_data_parallel_code_path_single_rank(hip_lib, tmp_path):
             assert (np.abs(va[k] - vb[k]) > 2e-5).mean() < 2e-3, k
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ PISTRec
+@pytest.mark.parametrize("B,L,NB,H", [(5, 10, 1, 1), (24, 50, 2, 2), (16, 100, 1, 4)])
+def test_pistrec_forward_and_gradients(hip_lib, tmp_path, B, L, NB, H):
+    """Time_Aware_self_Attention_model: logits, loss (no user L2 term), every gradient, clip norm."""
+    import oracle.c_oracle as co
+    import oracle.mtam_oracle as O
+    model, FLAGS, records = build(tmp_path, B, L, NB, H, model_name="PISTRec")
+    model.use_graph = False
+    p = model.path
+    arrays = {k: v.copy() for k, v in model.get_variables().items()}
+    feed = model.embedding.make_feed_dic_new(records)
+    bt = p.load_feed(feed)
+    p.eval_kernels(bt, 50)
+    logits, pred = bt.logits.cpu().numpy(), bt.pred.cpu().numpy()
+    out, grads, slot_sq = O.loss_and_grads("PISTRec", arrays, feed, H, NB, FLAGS.regulation_rate, torch.float64)
+    assert rel(logits, out["logits"].detach().numpy()) < LOGIT_TOL
+    chain = co.score_fma(pred, arrays["embedding_layer/item"])
+    assert np.array_equal(logits, chain)
+    k = min(50, logits.shape[1])
+    assert np.array_equal(bt.topk_idx.cpu().numpy()[:, :k], O.top_k(chain, k))
+
+    loss, summary = model.train(model.sess, records, 1e-3)
+    ref_loss = float(out["loss"].detach())
+    assert abs(loss - ref_loss) / abs(ref_loss) < 2e-5
+    got = p.grads_tf()
+    for name, g in grads.items():
+        if g is None:
+            assert name not in got or not np.any(got[name]), name      # user table: no gradient
+            continue
+        assert rel(got[name], g) < GRAD_TOL, name
+    ref_norm = O.global_norm(grads, slot_sq, "PISTRec", True)
+    assert abs(float(p.scale[1]) - ref_norm) / ref_norm < 1e-4
+
+
+def test_pistrec_adam_steps_track_the_oracle(hip_lib, tmp_path):
+    import oracle.mtam_oracle as O
+    B, L, NB, H = 32, 50, 2, 1
+    model, FLAGS, records = build(tmp_path, B, L, NB, H, model_name="PISTRec")
+    arrays = {k: v.copy() for k, v in model.get_variables().items()}
+    state = O.AdamState(arrays)
+    for step in range(3):
+        feed = model.embedding.make_feed_dic_new(records)
+        ref = O.train_step("PISTRec", arrays, state, feed, 1e-3, H, NB, FLAGS.regulation_rate,
+                           FLAGS.max_gradient_norm, True)
+        loss, _ = model.train(model.sess, records, 1e-3)
+        assert abs(loss - ref["loss"]) / abs(ref["loss"]) < 1e-4, step
+    got = model.get_variables()
+    for name, want in arrays.items():
+        dd = np.abs(got[name].astype(np.float64) - want)
+        assert dd.max() <= 2.1e-3 * 3, name
+        assert (dd > 2e-5).mean() < 2e-3, name
