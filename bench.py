@@ -27,7 +27,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3
-L, D, NB, H, B_PER_GPU = 50, 128, 1, 1, 128
+D = 128
+# headline workload (BASELINE.json configs[1]); the flags below select the other configurations
+L, NB, H, B_PER_GPU = 50, 1, 1, 128
 
 
 def gather_bytes_per_seq(L, D, e=4):
@@ -76,7 +78,7 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(records_batches, FLAGS, arrays, budget_s=15.0):
+def cpu_baseline(records_batches, FLAGS, arrays, budget_s=15.0, model_name="MTAM"):
     """Oracle (torch-CPU fp32, unfused, autograd) on the host cores: sequences/s."""
     import torch
     import oracle.mtam_oracle as O
@@ -92,7 +94,7 @@ def cpu_baseline(records_batches, FLAGS, arrays, budget_s=15.0):
     i = 0
     while True:
         t0 = time.perf_counter()
-        O.train_step("MTAM", arrays, state, feeds[i % len(feeds)], 1e-3, H, NB, FLAGS.regulation_rate,
+        O.train_step(model_name, arrays, state, feeds[i % len(feeds)], 1e-3, H, NB, FLAGS.regulation_rate,
                      FLAGS.max_gradient_norm, True)
         times.append(time.perf_counter() - t0)
         i += 1
@@ -113,7 +115,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--id-dist", default="zipf", choices=["zipf", "uniform"])
+    # non-headline configurations (BASELINE.json configs[2..]); defaults = the headline ml-1m workload
+    ap.add_argument("--model", default="MTAM", choices=["MTAM", "PISTRec"])
+    ap.add_argument("--items", type=int, default=0, help="catalog size (0: ml-1m's 3706)")
+    ap.add_argument("--seq-len", type=int, default=50)
+    ap.add_argument("--blocks", type=int, default=1)
+    ap.add_argument("--heads", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=128, help="sequences per GPU")
     args = ap.parse_args()
+    global L, NB, H, B_PER_GPU
+    L, NB, H, B_PER_GPU = args.seq_len, args.blocks, args.heads, args.batch
 
     import torch
     import torch.distributed as dist
@@ -141,19 +152,24 @@ def main():
         Behavior_embedding_time_aware_attention
     from mtamrecommender_amd.Model.base_model import Session
     from mtamrecommender_amd.Model.MTAMRec_model import MTAM
+    from mtamrecommender_amd.Model.PISTRec_model import Time_Aware_self_Attention_model
 
     FLAGS = model_parameter().get_parameter("MTAMb1_movielen").FLAGS
     FLAGS.num_blocks, FLAGS.num_heads, FLAGS.length_of_user_history = NB, H, L
     FLAGS.checkpoint_path_dir = "/tmp/mtam_bench_ckpt"
-    cat = SyntheticCatalog(seed=1234, **ML1M)
+    shape = dict(ML1M)
+    if args.items:
+        shape.update(item_count=args.items, category_count=max(301, min(1000, args.items // 1000)))
+    cat = SyntheticCatalog(seed=1234, **shape)
     emb = Behavior_embedding_time_aware_attention(True, cat.user_count, cat.item_count, cat.category_count, L,
                                                   seed=1234)
-    model = MTAM(FLAGS, emb, Session(device))
+    model = (MTAM if args.model == "MTAM" else Time_Aware_self_Attention_model)(FLAGS, emb, Session(device))
     p = model.path
     if world > 1:
         data_parallel.attach(p, world)
         data_parallel.broadcast_parameters(p)
-    arrays0 = model.get_variables() if rank == 0 else None
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    arrays0 = model.get_variables() if want_cpu else None
 
     # synthetic records: 32 distinct batches per rank, staged in HBM before the timed region
     n_batches = 32
@@ -217,8 +233,11 @@ def main():
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MTAMRec training step, ml-1m-shaped synthetic (3706 items, 301 categories, "
-                                   "4832 users), seq_len=50 emb=128 num_blocks=1 num_heads=1, batch=128 per GPU",
+            "config": {"workload": "%s training step, %s synthetic (%d items, %d categories, %d users), seq_len=%d "
+                                   "emb=128 num_blocks=%d num_heads=%d, batch=%d per GPU"
+                                   % ("MTAMRec" if args.model == "MTAM" else "PISTRec (Time_Aware_self_Attention_model)",
+                                      "ml-1m-shaped" if not args.items else "large-catalog", cat.item_count,
+                                      cat.category_count, cat.user_count, L, NB, H, B_PER_GPU),
                        "global_batch": B_PER_GPU * world, "seq_len": L, "parallelism": "dp%d" % world,
                        "id_dist": args.id_dist, "optimizer": "adam", "hipgraph": bool(model.use_graph)},
             "recall_at_20": recall, "loss_first": loss_first, "loss_last": loss_last,
@@ -231,7 +250,7 @@ def main():
                                      "bytes_per_launch": sb, "us_per_launch": t_scatter * 1e6},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(batches[:8], FLAGS, arrays0)
+            result["cpu_baseline"] = cpu_baseline(batches[:8], FLAGS, arrays0, model_name=args.model)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,123 @@
+"""Embedding gather / scatter-add roofline sweep (developer tool, GPU box only).
+
+    python3 tools/emb_roofline.py sweep            # graph-timed us/launch over batch x catalog sizes
+    python3 tools/emb_roofline.py pmc B V [N]      # N eager launches of each kernel (run under rocprofv3 --pmc)
+
+Algorithmic bytes follow SURVEY.md 8(d): gather (3L+1)(2*D*4+4) per sequence,
+scatter-add (3L+1)(3*D*4+4) per sequence, L = 50, D = 128, fp32.
+Ids follow bench.py's synthetic generator shape (Zipf items folded by modulo,
+fixed item->category map, positions 0..len-1, len ~ U{2..L}).
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from mtamrecommender_amd import hip_ops as ops  # noqa: E402
+
+L, D = 50, 128
+
+
+def make_case(B, V, dist="zipf", seed=1234, n_cat=304, n_user=4835):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sl = rng.integers(2, L + 1, size=B)
+    live = np.arange(L)[None, :] < sl[:, None]
+    if dist == "zipf":
+        items = np.mod(rng.zipf(1.1, size=(B, L)).astype(np.int64) - 1, V - 3)
+    else:
+        items = rng.integers(0, V - 3, size=(B, L))
+    cmap = rng.integers(0, n_cat - 3, size=V)
+    cats = cmap[items]
+    pos = np.tile(np.arange(L), (B, 1))
+    items, cats, pos = items * live, cats * live, pos * live
+    dev = "cuda"
+    t = lambda a, dt=torch.int32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    case = dict(B=B, V=V, item_ids=t(items), cat_ids=t(cats), pos_ids=t(pos),
+                user_ids=t(rng.integers(0, n_user, size=B)), seq_len=t(sl))
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev).uniform_(-0.2, 0.2)
+    case.update(item=f(V, D), cat=f(n_cat, D), pos=f(L + 3, D), user=f(n_user, D))
+    R = B * L
+    case.update(ic=f(R, 2 * D), pos_out=f(R, D), user_out=f(B, D), d_ic=f(R, 2 * D), d_pos=f(R, D),
+                l2=torch.zeros(ops.emb_gather_partials(B, L), device=dev),
+                sq=torch.zeros(ops.emb_scatter_partials(B, L), device=dev),
+                g_item=torch.zeros(V, D, device=dev), g_cat=torch.zeros(n_cat, D, device=dev),
+                g_pos=torch.zeros(L + 3, D, device=dev), g_user=torch.zeros(n_user, D, device=dev))
+    case["live_rows"] = int(live.sum()) * 3 + B
+    return case
+
+
+def gather(c):
+    ops.emb_gather_fwd(c["item"], c["cat"], c["pos"], c["user"], c["item_ids"], c["cat_ids"], c["pos_ids"],
+                       c["user_ids"], c["B"], L, 1, c["ic"], c["pos_out"], c["user_out"], c["l2"])
+
+
+def scatter(c):
+    ops.emb_scatter_add_bwd(c["d_ic"], c["d_pos"], c["ic"], c["pos_out"], c["user_out"], c["item_ids"],
+                            c["cat_ids"], c["pos_ids"], c["user_ids"], c["seq_len"], c["B"], L, 5e-5, 1,
+                            c["g_item"], c["g_cat"], c["g_pos"], c["g_user"], c["sq"])
+
+
+def graph_time(fn, reps, replays=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(replays):
+        g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e-3 / (reps * replays)
+
+
+def sweep():
+    out = []
+    for V in (3709, 1000003, 10000003):
+        for B in (128, 512, 2048, 8192):
+            for dist in ("zipf", "uniform"):
+                c = make_case(B, V, dist)
+                reps = 50 if B <= 512 else 10
+                tg = graph_time(lambda: gather(c), reps)
+                ts = graph_time(lambda: scatter(c), reps)
+                gb = (3 * L + 1) * (2 * D * 4 + 4) * B
+                sb = (3 * L + 1) * (3 * D * 4 + 4) * B
+                row = dict(V=V, B=B, dist=dist, gather_us=tg * 1e6, gather_GBs=gb / tg / 1e9,
+                           gather_frac_8TBs=gb / tg / 8e12, scatter_us=ts * 1e6, scatter_GBs_raw=sb / ts / 1e9,
+                           scatter_frac_8TBs_raw=sb / ts / 8e12,
+                           scatter_live_GBs=c["live_rows"] * (3 * D * 4 + 4) / ts / 1e9,
+                           atomic_added_GBs=c["live_rows"] * D * 4 / ts / 1e9)
+                out.append(row)
+                print(json.dumps(row), flush=True)
+                del c
+                torch.cuda.empty_cache()
+    return out
+
+
+def pmc(B, V, n):
+    c = make_case(B, V)
+    torch.cuda.synchronize()
+    for _ in range(n):
+        gather(c)
+        torch.cuda.synchronize()
+    for _ in range(n):
+        scatter(c)
+        torch.cuda.synchronize()
+    print(json.dumps(dict(B=B, V=V, launches=n, live_rows=c["live_rows"],
+                          gather_alg_bytes=(3 * L + 1) * (2 * D * 4 + 4) * B,
+                          scatter_alg_bytes=(3 * L + 1) * (3 * D * 4 + 4) * B)))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "sweep":
+        sweep()
+    else:
+        pmc(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 10)
