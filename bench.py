@@ -62,6 +62,21 @@ def time_kernel(fn, torch, reps=50, replays=20):
     return start.elapsed_time(stop) * 1e-3 / (reps * replays)
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, gfx950 read correction applied: tools/summarize_prof.py pmc).  PMC
+    counters cannot be collected inside this process, so the figure comes from the newest
+    profiles/r*_pmc_emb_*.json; None when no such file travels with the tree."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_emb_*.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))[kernel]["traffic_bytes"])
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def host_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -243,10 +258,12 @@ def main():
             "recall_at_20": recall, "loss_first": loss_first, "loss_last": loss_last,
             "roofline": {"kernel": "emb_gather_kernel", "bound": "hbm", "achieved": gb / t_gather / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / t_gather / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_launch": gb, "us_per_launch": t_gather * 1e6},
+                         "traffic": pmc_traffic("emb_gather_kernel") if (L, B_PER_GPU) == (50, 128) else None, "bytes_per_launch": gb, "us_per_launch": t_gather * 1e6},
             "roofline_scatter_add": {"kernel": "emb_scatter_kernel", "bound": "hbm", "achieved": sb / t_scatter / 1e9,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": sb / t_scatter / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                     "frac": sb / t_scatter / 1e9 / HBM_PEAK_GBS,
+                                     "traffic": pmc_traffic("emb_scatter_kernel")
+                                     if (L, B_PER_GPU) == (50, 128) else None,
                                      "bytes_per_launch": sb, "us_per_launch": t_scatter * 1e6},
         }
         if world == 1 and not args.no_cpu_baseline:

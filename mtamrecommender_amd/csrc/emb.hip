@@ -89,37 +89,36 @@ struct ScatterArgs {
   float *g_item, *g_cat, *g_pos, *g_user;
   int item_rows, cat_rows, pos_rows, user_rows;
   float *sq_partial;
-  int work_blocks;
+  int n_rm, n_tr, n_user;      // chunks: row-major (item, category), transposed (position), user
+  int n_partials;
 };
 
-// Wave slot s -> two consecutive rows of ONE table (wave-uniform choice):
-//   [0, P) item, [P, 2P) category, [2P, 3P) position with P = ceil(R/2); then ceil(B/2) user slots.
-// One half wave per row; lane li adds floats li, li+32, li+64, li+96 of the row, so every
-// atomic wave instruction covers two 128-B segments in two rows.
-__device__ __forceinline__ float scatter_row(const float *__restrict__ d, const float *__restrict__ e,
-                                             float *__restrict__ g, float reg, int li) {
-  float v[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int c = li + 32 * q;
-    v[q] = reg * e[c] + (d ? d[c] : 0.f);
-  }
-  float sq = 0.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    atomicAdd(g + li + 32 * q, v[q]);
-    sq += v[q] * v[q];
-  }
-  return sq;
-}
+// Scatter-add with a per-workgroup duplicate pre-reduction.
+//
+// Float atomics run at the memory side and serialise per 64-B line: with popularity-skewed ids
+// the hottest item/category row (hundreds of hits per batch) and the position rows (every sample
+// hits rows 0..len-1) set the kernel's duration, not the byte count.  So a workgroup owns a
+// chunk of CH = 64 slots of ONE table, finds the slots of its chunk that share a row
+// (leader = first slot with that id), sums those in LDS (ds_add_f32) and issues one global
+// atomic row per distinct id; slots that are alone in their chunk go straight from registers to
+// global atomics.  Chunks of the item and category tables are 64 consecutive (b, t) slots;
+// position chunks are 64 samples at ONE time index t, where the reference's data has a single
+// id (Prepare/mask_data_process.py:245-247).
+// Every atomic wave instruction still covers two 128-B segments in two rows (the full-rate shape).
+constexpr int CH = 64;
+constexpr int SLOTS_PER_HALF = CH / 8;
 
 __global__ __launch_bounds__(256) void emb_scatter_kernel(ScatterArgs p) {
-  const int lane = threadIdx.x & 63;
+  __shared__ float acc[CH][D];                 // 32 KB: sums of the rows that share an id
+  __shared__ int s_row[CH], s_id[CH], s_lead[CH], s_cnt[CH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const int half = lane >> 5, li = lane & 31;
+  const int wave_in_block = tid >> 6;
   const int R = p.B * p.L;
-  const int wave_in_block = threadIdx.x >> 6;
+  const int n_work = 2 * p.n_rm + p.n_tr + p.n_user;
 
-  if ((int)blockIdx.x == p.work_blocks) {
+  if ((int)blockIdx.x == n_work) {
     // Padded slots: every one of them holds row 0 of its table and a zero upstream
     // gradient, so their contributions collapse to n_pad * reg * row0 per table.
     if (wave_in_block != 0) return;
@@ -152,46 +151,119 @@ __global__ __launch_bounds__(256) void emb_scatter_kernel(ScatterArgs p) {
       }
     }
     sq = wave_sum(sq);
-    if (lane < 4) p.sq_partial[p.work_blocks * 4 + lane] = (lane == 0) ? sq : 0.f;
+    for (int i = n_work * 4 + lane; i < p.n_partials; i += 64) p.sq_partial[i] = (i == n_work * 4) ? sq : 0.f;
     return;
   }
 
-  const int wave_id = blockIdx.x * 4 + wave_in_block;
-  const int P = (R + 1) / 2;
-  const int total = 3 * P + (p.with_user ? (p.B + 1) / 2 : 0);
-  float sq = 0.f;
-  for (int i = 0; i < SLOTS_PER_WAVE; ++i) {
-    const int s = wave_id * SLOTS_PER_WAVE + i;          // wave-uniform
-    if (s >= total) break;
-    if (s < 3 * P) {
-      const int t = s / P;                                 // wave-uniform table
-      const int r = 2 * (s - t * P) + half;
-      bool live = r < R;
-      if (live) {
-        const int b = r / p.L;
-        live = (r - b * p.L) < min(max(p.seq_len[b], 0), p.L);
+  // ---- which table and which chunk (block-uniform)
+  int c = blockIdx.x, table;
+  if (c < p.n_rm) table = 0;
+  else if ((c -= p.n_rm) < p.n_rm) table = 1;
+  else if ((c -= p.n_rm) < p.n_tr) table = 2;
+  else { c -= p.n_tr; table = 3; }
+  const float *d_base, *e_base;
+  const int32_t *ids;
+  float *g;
+  int rows, stride;
+  if (table == 0)      { d_base = p.d_ic;     e_base = p.ic;     ids = p.item_ids; g = p.g_item; rows = p.item_rows; stride = 2 * D; }
+  else if (table == 1) { d_base = p.d_ic + D; e_base = p.ic + D; ids = p.cat_ids;  g = p.g_cat;  rows = p.cat_rows;  stride = 2 * D; }
+  else if (table == 2) { d_base = p.d_pos;    e_base = p.pos;    ids = p.pos_ids;  g = p.g_pos;  rows = p.pos_rows;  stride = D; }
+  else                 { d_base = nullptr;    e_base = p.user;   ids = p.user_ids; g = p.g_user; rows = p.user_rows; stride = D; }
+
+  // ---- slot -> gathered-row index (or -1: dead) and clamped id
+  if (tid < CH) {
+    int r = -1;
+    if (table <= 1) {
+      const int q = c * CH + tid;
+      if (q < R) {
+        const int b = q / p.L;
+        if (q - b * p.L < min(max(p.seq_len[b], 0), p.L)) r = q;
       }
-      if (live) {
-        if (t == 0) {
-          sq += scatter_row(p.d_ic + (size_t)r * 2 * D, p.ic + (size_t)r * 2 * D,
-                            p.g_item + (size_t)clamp_id(p.item_ids[r], p.item_rows) * D, p.reg, li);
-        } else if (t == 1) {
-          sq += scatter_row(p.d_ic + (size_t)r * 2 * D + D, p.ic + (size_t)r * 2 * D + D,
-                            p.g_cat + (size_t)clamp_id(p.cat_ids[r], p.cat_rows) * D, p.reg, li);
-        } else {
-          sq += scatter_row(p.d_pos + (size_t)r * D, p.pos + (size_t)r * D,
-                            p.g_pos + (size_t)clamp_id(p.pos_ids[r], p.pos_rows) * D, p.reg, li);
-        }
+    } else if (table == 2) {
+      const int t = c % p.L, b = (c / p.L) * CH + tid;
+      if (b < p.B && t < min(max(p.seq_len[b], 0), p.L)) r = b * p.L + t;
+    } else {
+      const int b = c * CH + tid;
+      if (b < p.B) r = b;
+    }
+    s_row[tid] = r;
+    s_id[tid] = r >= 0 ? clamp_id(ids[r], rows) : -1;
+  }
+  {
+    float4 *z = reinterpret_cast<float4 *>(&acc[0][0]);
+#pragma unroll
+    for (int i = 0; i < CH * D / 4 / 256; ++i) z[tid + 256 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+
+  // ---- every half wave loads its slots' rows (independent of the duplicate search below)
+  const int hw = wave_in_block * 2 + half;
+  float v[SLOTS_PER_HALF][4];
+  int my_row[SLOTS_PER_HALF];
+#pragma unroll
+  for (int k = 0; k < SLOTS_PER_HALF; ++k) {
+    const int s = hw + 8 * k;
+    const int r = s_row[s];
+    my_row[k] = r;
+    if (r >= 0) {
+      const float *e = e_base + (size_t)r * stride;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[k][q] = p.reg * e[li + 32 * q];
+      if (d_base) {
+        const float *d = d_base + (size_t)r * stride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[k][q] += d[li + 32 * q];
       }
     } else {
-      const int b = 2 * (s - 3 * P) + half;
-      if (b < p.B)
-        sq += scatter_row(nullptr, p.user + (size_t)b * D,
-                          p.g_user + (size_t)clamp_id(p.user_ids[b], p.user_rows) * D, p.reg, li);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[k][q] = 0.f;
     }
   }
+  // ---- leader (first slot of the chunk with the same id) and multiplicity
+  if (tid < CH) {
+    const int mine = s_id[tid];
+    int lead = tid, cnt = 0;
+    if (mine >= 0) {
+#pragma unroll 8
+      for (int j = 0; j < CH; ++j) {
+        const bool same = s_id[j] == mine;
+        cnt += same ? 1 : 0;
+        lead = (same && j < lead) ? j : lead;
+      }
+    }
+    s_lead[tid] = lead;
+    s_cnt[tid] = cnt;
+  }
+  __syncthreads();
+
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < SLOTS_PER_HALF; ++k) {
+    if (my_row[k] < 0) continue;
+    const int s = hw + 8 * k;
+    const int lead = s_lead[s];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sq += v[k][q] * v[k][q];
+    if (s_cnt[lead] > 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomicAdd(&acc[lead][li + 32 * q], v[k][q]);
+    } else {
+      float *gr = g + (size_t)s_id[s] * D;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomicAdd(gr + li + 32 * q, v[k][q]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SLOTS_PER_HALF; ++k) {
+    const int s = hw + 8 * k;
+    if (my_row[k] < 0 || s_lead[s] != s || s_cnt[s] <= 1) continue;
+    float *gr = g + (size_t)s_id[s] * D;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(gr + li + 32 * q, acc[s][li + 32 * q]);
+  }
   sq = wave_sum(sq);
-  if (lane == 0) p.sq_partial[wave_id] = sq;
+  if (lane == 0) p.sq_partial[blockIdx.x * 4 + wave_in_block] = sq;
 }
 
 int gather_waves(int B, int L) {
@@ -199,10 +271,11 @@ int gather_waves(int B, int L) {
   const int total = R + (R + B + 1) / 2;
   return (total + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE;
 }
+int scatter_rm_chunks(int B, int L) { return (B * L + CH - 1) / CH; }
+int scatter_tr_chunks(int B, int L) { return ((B + CH - 1) / CH) * L; }
+int scatter_user_chunks(int B) { return (B + CH - 1) / CH; }
 int scatter_work_blocks(int B, int L) {
-  const int slots = 3 * ((B * L + 1) / 2) + (B + 1) / 2;
-  const int waves = (slots + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE;
-  return (waves + 3) / 4;
+  return 2 * scatter_rm_chunks(B, L) + scatter_tr_chunks(B, L) + scatter_user_chunks(B);
 }
 
 }  // namespace
@@ -253,8 +326,10 @@ extern "C" int mtam_emb_scatter_add_bwd(const float *d_item_cat, const float *d_
   MTAM_CHECK_ARG(item_rows > 0 && cat_rows > 0 && pos_rows > 0 && user_rows > 0, "emb_scatter: empty table");
   ScatterArgs a{d_item_cat, d_pos, item_cat, pos, user, item_ids, cat_ids, pos_ids, user_ids, seq_len,
                 B, L, with_user, reg, g_item, g_cat, g_pos, g_user,
-                item_rows, cat_rows, pos_rows, user_rows, slot_sq_partial, scatter_work_blocks(B, L)};
-  hipLaunchKernelGGL(emb_scatter_kernel, dim3(a.work_blocks + 1), dim3(256), 0,
+                item_rows, cat_rows, pos_rows, user_rows, slot_sq_partial,
+                scatter_rm_chunks(B, L), scatter_tr_chunks(B, L), with_user ? scatter_user_chunks(B) : 0,
+                mtam_emb_scatter_partials(B, L)};
+  hipLaunchKernelGGL(emb_scatter_kernel, dim3(2 * a.n_rm + a.n_tr + a.n_user + 1), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("emb_scatter");
   return MTAM_OK;
