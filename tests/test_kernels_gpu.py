@@ -204,7 +204,7 @@ def test_emb_gather(ops, B, L, with_user):
     assert abs(float(part.double().sum()) - sq) / sq < 1e-6
 
 
-@pytest.mark.parametrize("B,L", [(1, 2), (5, 7), (128, 50)])
+@pytest.mark.parametrize("B,L", [(1, 2), (5, 7), (128, 50), (130, 9), (67, 50)])
 @pytest.mark.parametrize("with_user", [1, 0])
 def test_emb_scatter_add(ops, B, L, with_user):
     tabs, ids, uid, sl = _emb_case(B, L, B * 10 + L + 1)
