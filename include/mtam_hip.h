@@ -333,6 +333,19 @@ int mtam_adam_block(void);
 int mtam_adam(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
               const float *hyper, size_t sparse_begin, void *stream);
 
+/* The other choices of base_model.init_optimizer (Model/base_model.py:71-80):
+ * kind 0 GradientDescentOptimizer, 1 AdadeltaOptimizer (rho 0.95, eps 1e-8; slot1 = accum,
+ * slot2 = accum_update, both start at 0), 2 RMSPropOptimizer (decay 0.9, momentum 0, eps 1e-10;
+ * slot1 = rms starting at ONE, slot2 = momentum starting at 0) [TF1.14 training_ops formulas].
+ * p and the slots are updated from g * scale[0] with the raw learning rate lr[0] (device).
+ * Elements >= sparse_begin are tables (sparse kernel forms); in [sparse_begin, rowskip_end) a
+ * 128-float row whose gradient is entirely zero is not in the batch's IndexedSlices and is left
+ * untouched, slots included (TF applies sparse updates to the looked-up rows only).
+ */
+int mtam_opt_update(int kind, float *p, float *slot1, float *slot2, const float *g, size_t n,
+                    const float *scale, const float *lr, size_t sparse_begin, size_t rowskip_end,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

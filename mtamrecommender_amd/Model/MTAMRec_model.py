@@ -41,7 +41,8 @@ class MTAM(MTAMRec_model):
         device = getattr(self.sess, "device", "cuda:0")
         self.path = TimeAwarePath(self.embedding.tables(), live, L, self.num_heads, NB,
                                   self.regulation_rate, self.FLAGS.max_gradient_norm,
-                                  tf_compat_global_norm=self.FLAGS.tf_compat_global_norm, device=device)
+                                  tf_compat_global_norm=self.FLAGS.tf_compat_global_norm, device=device,
+                                  optimizer=self.opt)
         self.summery()
 
     # weight injection for parity tests / checkpoint interchange (TF names)

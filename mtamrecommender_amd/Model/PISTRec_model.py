@@ -38,7 +38,8 @@ class Time_Aware_self_Attention_model(PISTRec_model):
         device = getattr(self.sess, "device", "cuda:0")
         self.path = SelfAttentionPath(self.embedding.tables(), live, L, self.num_heads, NB,
                                       self.FLAGS.regulation_rate, self.FLAGS.max_gradient_norm,
-                                      tf_compat_global_norm=self.FLAGS.tf_compat_global_norm, device=device)
+                                      tf_compat_global_norm=self.FLAGS.tf_compat_global_norm, device=device,
+                                  optimizer=self.opt)
         self.summery()
 
     set_variables = MTAM.set_variables

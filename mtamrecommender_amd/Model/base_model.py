@@ -89,11 +89,10 @@ class base_model(object):
             pass
 
     def init_optimizer(self):
-        # The reference also offers adadelta / rmsprop / sgd (:71-80); every preset
-        # and the flag default use Adam, the only update the HIP path implements.
-        if self.FLAGS.optimizer != "adam":
-            raise NotImplementedError("optimizer %r: only 'adam' has a HIP kernel" % self.FLAGS.optimizer)
-        self.opt = "adam"
+        # Model/base_model.py:71-80: 'adadelta', 'adam', 'rmsprop', anything else -> plain SGD.
+        # Each has a HIP update kernel (mtam_adam / mtam_opt_update).
+        name = self.FLAGS.optimizer
+        self.opt = name if name in ("adadelta", "adam", "rmsprop") else "sgd"
 
     def build_model(self):
         pass

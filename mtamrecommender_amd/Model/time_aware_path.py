@@ -114,11 +114,14 @@ class TimeAwarePath(object):
     BATCH_CLASS = None       # set below
 
     def __init__(self, tables, dense_tf, L, num_heads, num_blocks, regulation_rate, max_gradient_norm,
-                 tf_compat_global_norm=True, device="cuda:0"):
+                 tf_compat_global_norm=True, device="cuda:0", optimizer="adam"):
         self.device = dev = torch.device(device)
         self.L, self.H, self.NB = L, num_heads, num_blocks
         self.reg, self.clip = float(regulation_rate), float(max_gradient_norm)
         self.tf_compat = bool(tf_compat_global_norm)
+        if optimizer not in ("adam", "sgd", "adadelta", "rmsprop"):
+            raise ValueError("unknown optimizer %r" % (optimizer,))
+        self.optimizer = optimizer
         self.layout = DenseLayout(self.MODEL, D, L, num_blocks)
         for k, v in tables.items():
             if v.shape[1] != D:
@@ -148,6 +151,8 @@ class TimeAwarePath(object):
             self.tables[k].copy_(torch.from_numpy(np.ascontiguousarray(tables[k], dtype=np.float32)))
         # everything before the item gradient is zeroed per step (the item gradient is overwritten
         # by the dense scoring GEMM)
+        if optimizer == "rmsprop":
+            self.flat_m.fill_(1.0)      # the "rms" slot starts at one [TF1.14 RMSPropOptimizer._create_slots]
         self.zero_prefix = self.flat_g[:self.tab_off["item"]]
         self.nb_dense = ops.sqnorm_blocks(self.n_dense)
         self.nb_item = ops.sqnorm_blocks(self.tables["item"].numel())
@@ -344,8 +349,13 @@ class TimeAwarePath(object):
         ops.sqnorm_clip_scale(self.flat_g, n_g, part, 0, n, self.clip, self.scale, bt.feed["lr"],
                               self.adam_state, self.ticket, bt.l2_partial, bt.l2_partial.numel(), bt.ce, bt.B,
                               self.reg, 1.0 / gb, bt.loss)
-        ops.adam(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,
-                 self.adam_state, self.n_dense)
+        if self.optimizer == "adam":
+            ops.adam(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,
+                     self.adam_state, self.n_dense)
+        else:
+            # sparse (row-skipping) region: category, position, user; the item gradient has every row
+            ops.opt_update(self.optimizer, self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total,
+                           self.scale, bt.feed["lr"], self.n_dense, self.tab_off["item"])
 
     def forward_backward_kernels(self, bt):
         self.forward(bt, training=True)

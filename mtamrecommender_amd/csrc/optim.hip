@@ -185,6 +185,79 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
   }
 }
 
+// The reference's other optimizer choices (Model/base_model.py:71-80): GradientDescent, Adadelta
+// (rho 0.95, eps 1e-8) and RMSProp (decay 0.9, momentum 0, eps 1e-10) with the TF 1.14 update
+// formulas [TF1.14 training_ops].  Tables receive IndexedSlices gradients, so TF applies the
+// sparse kernels to the rows that occur in the batch only: slots of rows outside the batch do not
+// decay.  Elements in [sparse_begin, rowskip_end) are such tables (category, position, user): a
+// 128-float row whose summed gradient is entirely zero is left untouched.  The item table (at and
+// after rowskip_end) has every row in its IndexedSlices (dense scoring gradient).
+enum { OPT_SGD = 0, OPT_ADADELTA = 1, OPT_RMSPROP = 2 };
+
+template <int KIND>
+__global__ __launch_bounds__(256) void opt_kernel(float *__restrict__ p, float *__restrict__ s1,
+                                                  float *__restrict__ s2, const float *__restrict__ g, size_t n,
+                                                  const float *__restrict__ scale, const float *__restrict__ lr_ptr,
+                                                  size_t sparse_begin, size_t rowskip_end) {
+  const float sc = scale[0];
+  const float lr = lr_ptr[0];
+  const size_t base = (size_t)blockIdx.x * NORM_BLOCK;
+  const bool sparse_form = base >= sparse_begin;
+  const bool rowskip = sparse_form && base < rowskip_end;
+  auto step = [&](float &pp, float &a, float &b, float gg) {
+    gg *= sc;
+    if (KIND == OPT_SGD) {
+      pp -= lr * gg;
+    } else if (KIND == OPT_ADADELTA) {
+      const float rho = 0.95f, eps = 1e-8f;
+      a = a * rho + (gg * gg) * (1.0f - rho);
+      const float upd = sqrtf(b + eps) * (1.0f / sqrtf(a + eps)) * gg;
+      pp -= upd * lr;
+      b = b * rho + (upd * upd) * (1.0f - rho);
+    } else {
+      const float rho = 0.9f, eps = 1e-10f;
+      if (sparse_form) a = a * rho + (gg * gg) * (1.0f - rho);
+      else a = a + (gg * gg - a) * (1.0f - rho);
+      b = (gg * lr) / sqrtf(a + eps);          // momentum 0: mom = mom * 0 + lr * g / sqrt(ms + eps)
+      pp -= b;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NORM_BLOCK / 1024; ++i) {
+    const size_t o = base + (size_t)(threadIdx.x + 256 * i) * 4;
+    if (o + 3 < n) {
+      const float4 gv = *reinterpret_cast<const float4 *>(g + o);
+      if (rowskip) {       // 32 consecutive lanes hold one 128-float row
+        const bool nz = gv.x != 0.f || gv.y != 0.f || gv.z != 0.f || gv.w != 0.f;
+        const unsigned long long m = __ballot(nz);
+        const unsigned half = (threadIdx.x & 32) ? (unsigned)(m >> 32) : (unsigned)m;
+        if (half == 0u) continue;
+      }
+      float4 pv = *reinterpret_cast<float4 *>(p + o);
+      float4 av = make_float4(0.f, 0.f, 0.f, 0.f), bv = av;
+      if (KIND != OPT_SGD) {
+        av = *reinterpret_cast<float4 *>(s1 + o);
+        bv = *reinterpret_cast<float4 *>(s2 + o);
+      }
+      step(pv.x, av.x, bv.x, gv.x);
+      step(pv.y, av.y, bv.y, gv.y);
+      step(pv.z, av.z, bv.z, gv.z);
+      step(pv.w, av.w, bv.w, gv.w);
+      *reinterpret_cast<float4 *>(p + o) = pv;
+      if (KIND != OPT_SGD) {
+        *reinterpret_cast<float4 *>(s1 + o) = av;
+        *reinterpret_cast<float4 *>(s2 + o) = bv;
+      }
+    } else {
+      for (size_t q = o; q < n && q < o + 4; ++q) {
+        float a = KIND != OPT_SGD ? s1[q] : 0.f, b = KIND != OPT_SGD ? s2[q] : 0.f;
+        step(p[q], a, b, g[q]);
+        if (KIND != OPT_SGD) { s1[q] = a; s2[q] = b; }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int mtam_sqnorm_blocks(size_t n) { return (int)((n + NORM_BLOCK - 1) / NORM_BLOCK); }
@@ -239,5 +312,29 @@ extern "C" int mtam_adam(float *p, float *m, float *v, const float *g, size_t n,
   hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n, scale,
                      hyper, sparse_begin);
   MTAM_CHECK_LAUNCH("adam");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_opt_update(int kind, float *p, float *slot1, float *slot2, const float *g, size_t n,
+                               const float *scale, const float *lr, size_t sparse_begin, size_t rowskip_end,
+                               void *stream) {
+  MTAM_CHECK_ARG(kind >= OPT_SGD && kind <= OPT_RMSPROP, "opt_update: kind must be 0 (sgd), 1 (adadelta) or 2 (rmsprop)");
+  MTAM_CHECK_ARG(p && g && scale && lr && n > 0, "opt_update: bad arguments");
+  MTAM_CHECK_ARG(kind == OPT_SGD || (slot1 && slot2), "opt_update: adadelta / rmsprop need two slot buffers");
+  MTAM_CHECK_ARG(mtam_aligned16(p) && mtam_aligned16(g) && mtam_aligned16(slot1) && mtam_aligned16(slot2),
+                 "opt_update: buffers must be 16-byte aligned");
+  MTAM_CHECK_ARG(sparse_begin >= n || sparse_begin % NORM_BLOCK == 0,
+                 "opt_update: sparse_begin must be a multiple of %d (or >= n)", NORM_BLOCK);
+  MTAM_CHECK_ARG(rowskip_end >= sparse_begin && (rowskip_end - sparse_begin) % 128 == 0,
+                 "opt_update: the row-sparse region must be whole 128-float rows");
+  dim3 grid(mtam_sqnorm_blocks(n));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (kind == OPT_SGD)
+    hipLaunchKernelGGL(opt_kernel<OPT_SGD>, grid, dim3(256), 0, st, p, slot1, slot2, g, n, scale, lr, sparse_begin, rowskip_end);
+  else if (kind == OPT_ADADELTA)
+    hipLaunchKernelGGL(opt_kernel<OPT_ADADELTA>, grid, dim3(256), 0, st, p, slot1, slot2, g, n, scale, lr, sparse_begin, rowskip_end);
+  else
+    hipLaunchKernelGGL(opt_kernel<OPT_RMSPROP>, grid, dim3(256), 0, st, p, slot1, slot2, g, n, scale, lr, sparse_begin, rowskip_end);
+  MTAM_CHECK_LAUNCH("opt_update");
   return MTAM_OK;
 }

@@ -256,6 +256,15 @@ def adam(p, m, v, g, n, scale, hyper, sparse_begin):
                              _stream()), "mtam_adam")
 
 
+OPT_KINDS = {"sgd": 0, "adadelta": 1, "rmsprop": 2}
+
+
+def opt_update(kind, p, slot1, slot2, g, n, scale, lr, sparse_begin, rowskip_end):
+    lib = _lib.load()
+    _lib.check(lib.mtam_opt_update(OPT_KINDS[kind], _p(p), _p(slot1), _p(slot2), _p(g), n, _p(scale), _p(lr),
+                                   int(sparse_begin), int(rowskip_end), _stream()), "mtam_opt_update")
+
+
 def gemm_tn_atomic_grouped(problems):
     """problems: list of dicts(A, lda, B, ldb, C, ldc, M, N, K, split_k) with device tensors."""
     lib = _lib.load()

@@ -270,15 +270,74 @@ class AdamState(object):
         self.beta2_power = np.float32(0.999)
 
 
+class SlotState(object):
+    """Slots of the reference's other optimizers (Model/base_model.py:71-80) [TF1.14]:
+    adadelta: accum, accum_update (zeros); rmsprop: rms (ONES), momentum (zeros); sgd: none."""
+
+    def __init__(self, kind, arrays):
+        assert kind in ("sgd", "adadelta", "rmsprop")
+        self.kind = kind
+        one = kind == "rmsprop"
+        self.s1 = {k: (np.ones_like(v) if one else np.zeros_like(v)) for k, v in arrays.items()}
+        self.s2 = {k: np.zeros_like(v) for k, v in arrays.items()}
+
+
+ROW_SPARSE = {"embedding_layer/category": "category_list", "embedding_layer/position": "position_list",
+              "embedding_layer/user": "user_id"}
+
+
+def apply_slot_optimizer(arrays, state, grads, scale, lr, feed):
+    """GradientDescent / Adadelta (rho .95, eps 1e-8) / RMSProp (decay .9, momentum 0, eps 1e-10)
+    .apply_gradients [TF1.14 training_ops].  The looked-up tables get IndexedSlices gradients: the
+    sparse kernels run on the rows present in the batch only (after summing duplicates); the item
+    table's IndexedSlices holds every row (dense scoring gradient concatenated with the lookups)."""
+    f = np.float32
+    lr = f(lr)
+    for k, g in grads.items():
+        if g is None:
+            continue
+        g = (g * scale).astype(np.float32)
+        if k in ROW_SPARSE:
+            rows = np.unique(np.asarray(feed[ROW_SPARSE[k]]).ravel())
+        else:
+            rows = slice(None)
+        p, a, b, gg = arrays[k][rows], state.s1[k][rows], state.s2[k][rows], g[rows]
+        if state.kind == "sgd":
+            p = p - lr * gg
+        elif state.kind == "adadelta":
+            rho, eps = f(0.95), f(1e-8)
+            a = a * rho + (gg * gg) * (f(1) - rho)
+            upd = np.sqrt(b + eps) * (f(1) / np.sqrt(a + eps)) * gg
+            p = p - upd * lr
+            b = b * rho + (upd * upd) * (f(1) - rho)
+        else:
+            rho, eps = f(0.9), f(1e-10)
+            if k.startswith("embedding_layer/"):
+                a = a * rho + (gg * gg) * (f(1) - rho)            # SparseApplyRMSProp form
+            else:
+                a = a + (gg * gg - a) * (f(1) - rho)              # ApplyRMSProp form
+            b = (gg * lr) / np.sqrt(a + eps)                      # momentum = 0
+            p = p - b
+        arrays[k][rows] = p.astype(np.float32)
+        state.s1[k][rows] = a.astype(np.float32)
+        state.s2[k][rows] = b.astype(np.float32)
+
+
 def train_step(model, arrays, state, feed, lr, num_heads, num_blocks, regulation_rate,
                max_gradient_norm=1.0, tf_compat_norm=True, global_batch=None):
     """One ``sess.run([loss, merged, train_op])`` (Model/base_model.py:150-167,290-297):
-    gradients -> clip_by_global_norm -> Adam.  Updates ``arrays``/``state`` in place."""
+    gradients -> clip_by_global_norm -> optimizer (Adam for an AdamState, else the SlotState's kind).
+    Updates ``arrays``/``state`` in place."""
     out, grads, slot_sq = loss_and_grads(model, arrays, feed, num_heads, num_blocks,
                                          regulation_rate, torch.float32, global_batch)
     norm = np.float32(global_norm(grads, slot_sq, model, tf_compat_norm))
     c = np.float32(max_gradient_norm)
     scale = c * min(np.float32(1.0) / norm, np.float32(1.0) / c)          # clip_by_global_norm [TF1.14]
+    if isinstance(state, SlotState):
+        apply_slot_optimizer(arrays, state, grads, scale, lr, feed)
+        return dict(loss=float(out["loss"].detach()), ce_mean=float(out["ce"].detach().mean()),
+                    l2=float(out["l2"].detach()), global_norm=float(norm), scale=float(scale),
+                    logits=out["logits"].detach().numpy(), pred=out["pred"].detach().numpy(), grads=grads)
     b1, b2, eps = np.float32(0.9), np.float32(0.999), np.float32(1e-8)
     lr32 = np.float32(lr)                                                 # lr placeholder is f64, cast to var dtype
     lr_t = lr32 * np.sqrt(np.float32(1) - state.beta2_power) / (np.float32(1) - state.beta1_power)

@@ -643,3 +643,35 @@ def test_grouped_weight_gradient_gemm_and_colsum(ops):
     ops.colsum_atomic_multi(jobs)
     for (_, _, _, _, out), want in zip(jobs, wants):
         assert rel_err(out.cpu().numpy(), want) < 1e-5
+
+
+# ------------------------------------------------- sgd / adadelta / rmsprop
+@pytest.mark.parametrize("kind", ["sgd", "adadelta", "rmsprop"])
+def test_opt_update_matches_the_tf_formulas(ops, kind):
+    """mtam_opt_update vs oracle.apply_slot_optimizer on one flat buffer laid out like the model's:
+    [dense 4096 | row-sparse table 40 rows | dense-gradient table 24 rows]."""
+    import oracle.mtam_oracle as O
+    rng = np.random.default_rng(11)
+    nd, r1, r2 = 4096, 40, 24
+    arrays = {"w": rng.standard_normal(nd).astype(np.float32),
+              "embedding_layer/category": rng.standard_normal((r1, D)).astype(np.float32),
+              "embedding_layer/item": rng.standard_normal((r2, D)).astype(np.float32)}
+    touched = np.array([0, 3, 4, 17, 39])
+    state = O.SlotState(kind, arrays)
+    flat = lambda d: np.concatenate([d["w"], d["embedding_layer/category"].ravel(), d["embedding_layer/item"].ravel()])
+    p = dev(flat(arrays))
+    s1, s2 = dev(flat(state.s1)), dev(flat(state.s2))
+    scale = dev(np.array([0.37, 0.0], np.float32))
+    lr = dev(np.array([0.05, 0, 0, 0], np.float32))
+    for step in range(3):
+        grads = {"w": rng.standard_normal(nd).astype(np.float32),
+                 "embedding_layer/category": np.zeros((r1, D), np.float32),
+                 "embedding_layer/item": rng.standard_normal((r2, D)).astype(np.float32)}
+        grads["embedding_layer/category"][touched] = rng.standard_normal((len(touched), D)).astype(np.float32)
+        O.apply_slot_optimizer(arrays, state, grads, np.float32(0.37), 0.05, {"category_list": touched})
+        ops.opt_update(kind, p, s1, s2, dev(flat(grads)), p.numel(), scale, lr, nd, nd + r1 * D)
+        touched = np.array([1, 3, 20])
+    assert rel_err(p.cpu().numpy(), flat(arrays)) < 2e-6
+    if kind != "sgd":
+        assert rel_err(s1.cpu().numpy(), flat(state.s1)) < 2e-6
+        assert rel_err(s2.cpu().numpy(), flat(state.s2)) < 2e-5

@@ -265,3 +265,32 @@ def test_oracle_reproduces_golden(path):
     for k in gold.files:
         if k.startswith("grad/"):
             assert np.allclose(grads[k[5:]], gold[k], rtol=1e-9, atol=1e-13), k
+
+
+def test_slot_optimizers_known_answers():
+    """One scalar step of each TF 1.14 formula, worked by hand (g = 2, scale = 0.5 -> 1, lr = 0.1)."""
+    import oracle.mtam_oracle as O
+    for kind, want_p, want_s1, want_s2 in (
+            ("sgd", 1.0 - 0.1 * 1.0, None, None),
+            # accum = .05; update = sqrt(1e-8) / sqrt(.05 + 1e-8) * 1; accum_update = .05 * update^2
+            ("adadelta", 1.0 - 0.1 * (1e-4 / np.sqrt(0.05 + 1e-8)), 0.05, 0.05 * (1e-4 / np.sqrt(0.05 + 1e-8)) ** 2),
+            # dense form: ms = 1 + (1 - 1) * .1 = 1; mom = .1 * 1 / sqrt(1 + 1e-10)
+            ("rmsprop", 1.0 - 0.1 / np.sqrt(1.0 + 1e-10), 1.0, 0.1 / np.sqrt(1.0 + 1e-10))):
+        arrays = {"w": np.array([1.0], np.float32)}
+        st = O.SlotState(kind, arrays)
+        O.apply_slot_optimizer(arrays, st, {"w": np.array([2.0], np.float32)}, np.float32(0.5), 0.1, {})
+        assert abs(arrays["w"][0] - want_p) < 1e-6, kind
+        if want_s1 is not None:
+            assert abs(st.s1["w"][0] - want_s1) < 1e-7 and abs(st.s2["w"][0] - want_s2) < 1e-8, kind
+    # row-sparse tables: rows outside the batch keep parameters AND slots; duplicates are summed first
+    arrays = {"embedding_layer/category": np.ones((4, 2), np.float32)}
+    st = O.SlotState("rmsprop", arrays)
+    st.s1["embedding_layer/category"][:] = 0.5
+    g = np.zeros((4, 2), np.float32)
+    g[2] = 3.0
+    O.apply_slot_optimizer(arrays, st, {"embedding_layer/category": g}, np.float32(1.0), 0.1, {"category_list": [2, 2]})
+    assert np.all(st.s1["embedding_layer/category"][[0, 1, 3]] == 0.5)
+    assert np.all(arrays["embedding_layer/category"][[0, 1, 3]] == 1.0)
+    ms = 0.5 * 0.9 + 9.0 * 0.1          # sparse form
+    assert np.allclose(st.s1["embedding_layer/category"][2], ms, rtol=1e-6)
+    assert np.allclose(arrays["embedding_layer/category"][2], 1.0 - 0.3 / np.sqrt(ms + 1e-10), rtol=1e-6)
