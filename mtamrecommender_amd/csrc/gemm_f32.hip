@@ -13,6 +13,11 @@
 // (straight-line 16-B loads on the wave-uniform fast path), one barrier per tile.
 #include "common.h"
 
+#ifndef GEMM_STAMP          // tools/gemm_lab.hip defines these to read where a kernel's cycles go
+#define GEMM_STAMP(i)
+#define GEMM_STAMP_DECL
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
@@ -114,6 +119,61 @@ __device__ __forceinline__ void store_ccontig(float *__restrict__ S, const float
 
 constexpr int TILE_FLOATS = BK * LDM;   // one operand tile in LDS
 
+// One wave's 32x32 accumulator -> C with the fused epilogue.
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+// Epilogues that read (C, bias rows, aux_in) issue ALL their loads before the first store: written
+// as load-compute-store per row, possible aliasing made the compiler wait out a full memory round
+// trip per row (16 rows: 12,000 cycles for RELU_ADD, 36,000 for ACCUM2_MASK, tools/gemm_lab.hip).
+template <int EPI>
+__device__ __forceinline__ void store_acc(const GemmArgs &p, const f32x16 &acc, int row0, int gn, int lane) {
+  if (gn >= p.N) return;
+  constexpr bool READ_C = EPI == MTAM_EPI_ACCUM || EPI == MTAM_EPI_ACCUM_MASK || EPI == MTAM_EPI_ACCUM2_MASK;
+  constexpr bool READ_AUX = EPI == MTAM_EPI_RELU_ADD || EPI == MTAM_EPI_ACCUM_MASK || EPI == MTAM_EPI_ACCUM2_MASK;
+  constexpr bool READ_BIAS2 = EPI == MTAM_EPI_ACCUM2_MASK;
+  float bias = 0.f;
+  if (EPI == MTAM_EPI_BIAS || EPI == MTAM_EPI_BIAS_RELU) bias = p.bias[gn];
+  const int rbase = row0 + 4 * (lane >> 5);
+  float cv[16], av[16], bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gm = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);      // clamped: ragged rows are not stored below
+    if (READ_C) cv[r] = p.C[(size_t)gm * p.ldc + gn];
+    if (READ_AUX) av[r] = p.aux_in[(size_t)gm * p.ld_aux + gn];
+    if (READ_BIAS2) bv[r] = p.bias[(size_t)gm * p.ld_aux + gn];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gm = rbase + (r & 3) + 8 * (r >> 2);
+    if (gm >= p.M) continue;
+    float v = acc[r];
+    float *c = p.C + (size_t)gm * p.ldc + gn;
+    const size_t o = (size_t)gm * p.ld_aux + gn;
+    if (EPI == MTAM_EPI_STORE) {
+      *c = v;
+    } else if (EPI == MTAM_EPI_BIAS) {
+      *c = v + bias;
+    } else if (EPI == MTAM_EPI_BIAS_RELU) {
+      *c = fmaxf(v + bias, 0.f);
+    } else if (EPI == MTAM_EPI_RELU_ADD) {
+      v = fmaxf(v, 0.f);
+      p.aux_out[o] = v;
+      *c = v + av[r];
+    } else if (EPI == MTAM_EPI_ACCUM) {
+      *c = cv[r] + v;
+    } else if (EPI == MTAM_EPI_ACCUM_MASK) {
+      v += cv[r];
+      *c = v;
+      p.aux_out[o] = (av[r] > 0.f) ? v : 0.f;
+    } else if (EPI == MTAM_EPI_ACCUM2_MASK) {
+      v += cv[r] + bv[r];
+      *c = v;
+      p.aux_out[o] = (av[r] > 0.f) ? v : 0.f;
+    } else {  // MTAM_EPI_ATOMIC
+      atomicAdd(c, v);
+    }
+  }
+}
+
 // One 64x64 output tile over one K slice.  LDS: As[2][TILE_FLOATS], Bs[2][TILE_FLOATS]
 // (double buffered: the tile for step kt+1 is written while step kt is multiplied; one barrier per step).
 template <bool TA, bool TB, int EPI>
@@ -161,13 +221,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
 
   if (kbeg < kend) {
     const int nk = (kend - kbeg + BK - 1) / BK;
-    load_tiles(kbeg);
-    store_tiles(0);
-    if (nk > 1) load_tiles(kbeg + BK);
-    __syncthreads();
     const int a_off = (lane >> 5) * LDA_S + wm * 32 + (lane & 31);
     const int b_off = (lane >> 5) * LDB_S + wn * 32 + (lane & 31);
-    for (int kt = 0; kt < nk; ++kt) {
+    auto multiply = [&](int kt) {
       const float *a_s = As + (kt & 1) * TILE_FLOATS + a_off;
       const float *b_s = Bs + (kt & 1) * TILE_FLOATS + b_off;
       float fa[BK / 2], fb[BK / 2];
@@ -176,54 +232,69 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
         fa[q] = a_s[2 * q * LDA_S];
         fb[q] = b_s[2 * q * LDB_S];
       }
+      GEMM_STAMP(1);
 #pragma unroll
       for (int q = 0; q < BK / 2; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
-      if (kt + 1 < nk) {
-        store_tiles((kt + 1) & 1);                       // registers hold tile kt+1 (loaded one step ago)
-        if (kt + 2 < nk) load_tiles(kbeg + (kt + 2) * BK);
-      }
+      GEMM_STAMP(2);
+    };
+    GEMM_STAMP_DECL;
+    if (fullA && fullB && (kend - kbeg) % BK == 0) {
+      // Every tile in range: a straight-line loop body.  The 16 MFMAs of a k-tile are one dependent
+      // chain (a new one issues every ~84 cycles, tools/gemm_lab.hip), so the next tile's LDS writes
+      // and the global loads of the tile after it are placed INTO those gaps instead of after the
+      // chain, where a lone wave per SIMD ran them un-overlapped (1,100 of 2,900 cycles per k-tile).
+      auto load_fast = [&](int k0) {
+        if (TA) load_ccontig<true>(p.A, p.lda, p.M, m0, k0, kend, ra);
+        else    load_kcontig<true>(p.A, p.lda, p.M, m0, k0, kend, ra);
+        if (TB) load_kcontig<true>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+        else    load_ccontig<true>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+      };
+      constexpr int N_DSW = (TA ? 2 : 4) + (TB ? 4 : 2);     // ds_write2_b32 pairs / ds_write_b128 per k-tile
+      load_fast(kbeg);
+      store_tiles(0);
+      if (nk > 1) load_fast(kbeg + BK);
       __syncthreads();
+      int kt = 0;
+      for (; kt + 2 < nk; ++kt) {
+        GEMM_STAMP(0);
+        multiply(kt);
+        store_tiles((kt + 1) & 1);
+        load_fast(kbeg + (kt + 2) * BK);
+#pragma unroll
+        for (int i = 0; i < BK / 2; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
+          if (i >= 2 && i < 2 + N_DSW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+          if (i >= 10 && i < 14) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+        }
+        GEMM_STAMP(3);
+        __syncthreads();
+        GEMM_STAMP(4);
+      }
+      for (; kt < nk; ++kt) {
+        multiply(kt);
+        if (kt + 1 < nk) store_tiles((kt + 1) & 1);
+        __syncthreads();
+      }
+    } else {
+      load_tiles(kbeg);
+      store_tiles(0);
+      if (nk > 1) load_tiles(kbeg + BK);
+      __syncthreads();
+      for (int kt = 0; kt < nk; ++kt) {
+        GEMM_STAMP(0);
+        multiply(kt);
+        if (kt + 1 < nk) {
+          store_tiles((kt + 1) & 1);                       // registers hold tile kt+1 (loaded one step ago)
+          if (kt + 2 < nk) load_tiles(kbeg + (kt + 2) * BK);
+        }
+        GEMM_STAMP(3);
+        __syncthreads();
+        GEMM_STAMP(4);
+      }
     }
   }
 
-  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const int gn = n0 + wn * 32 + (lane & 31);
-  if (gn >= p.N) return;
-  float bias = 0.f;
-  if (EPI == MTAM_EPI_BIAS || EPI == MTAM_EPI_BIAS_RELU) bias = p.bias[gn];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (gm >= p.M) continue;
-    float v = acc[r];
-    float *c = p.C + (size_t)gm * p.ldc + gn;
-    if (EPI == MTAM_EPI_STORE) {
-      *c = v;
-    } else if (EPI == MTAM_EPI_BIAS) {
-      *c = v + bias;
-    } else if (EPI == MTAM_EPI_BIAS_RELU) {
-      *c = fmaxf(v + bias, 0.f);
-    } else if (EPI == MTAM_EPI_RELU_ADD) {
-      const size_t o = (size_t)gm * p.ld_aux + gn;
-      v = fmaxf(v, 0.f);
-      p.aux_out[o] = v;
-      *c = v + p.aux_in[o];
-    } else if (EPI == MTAM_EPI_ACCUM) {
-      *c += v;
-    } else if (EPI == MTAM_EPI_ACCUM_MASK) {
-      const size_t o = (size_t)gm * p.ld_aux + gn;
-      v += *c;
-      *c = v;
-      p.aux_out[o] = (p.aux_in[o] > 0.f) ? v : 0.f;
-    } else if (EPI == MTAM_EPI_ACCUM2_MASK) {
-      const size_t o = (size_t)gm * p.ld_aux + gn;
-      v += *c + p.bias[o];
-      *c = v;
-      p.aux_out[o] = (p.aux_in[o] > 0.f) ? v : 0.f;
-    } else {  // MTAM_EPI_ATOMIC
-      atomicAdd(c, v);
-    }
-  }
+  store_acc<EPI>(p, acc, m0 + wm * 32, n0 + wn * 32 + (lane & 31), lane);
 }
 
 template <bool TA, bool TB, int EPI>
