@@ -1,0 +1,72 @@
+/* mtam_host.h -- C ABI of libmtam_host.so: the host side of the batch feed.
+ *
+ * Replaces, for the time-aware path, what the reference does in Python per training step:
+ *   - `eval(line)` over train_data.txt / test_data.txt      Prepare/prepare_data_base.py:79-92
+ *   - DataHandle.get_input_data.DataInput (missing from the reference tree; contract fixed by its use
+ *     at train_process.py:240,326: sequential non-overlapping slices, short final batch)
+ *   - Embedding.make_feed_dic_new: six np.pad calls per record, pad value 0 at the END, to
+ *     length_of_user_history                   Embedding/Behavior_embedding_time_aware_attention.py:146-192
+ * One record is the 9-tuple of Prepare/prepare_data_base.py:252-314:
+ *   (user_id, item_list, category_list, time_list, timelast_list, timenow_list, position_list,
+ *    [target_id, target_category, target_time], length)
+ * Records are held in structure-of-arrays form; a batch is written straight into the int32-word feed
+ * arena the device step reads (one pinned buffer, one H2D copy), with the range checks TF's CPU gather
+ * would raise on.  Plain C, no torch / HIP types; every function is thread-safe on a built record set.
+ */
+#ifndef MTAM_HOST_H
+#define MTAM_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct MtamRecordSet MtamRecordSet;
+
+/* Word offsets of each field inside one feed arena (4-byte words; floats are stored bit-wise). */
+typedef struct {
+  int user_id, item_list, category_list, position_list, target_item_id, seq_length;
+  int time_list, timelast_list, target_item_time, lr;
+  int words; /* total arena size in words */
+} MtamArenaLayout;
+
+/* Row counts of the four tables (count + 3 each): ids outside [0, rows) are an error, as in TF. */
+typedef struct {
+  int item_rows, category_rows, position_rows, user_rows;
+} MtamTableRows;
+
+/* Parse a train_data.txt / test_data.txt file (one str(tuple) per line).  NULL + message on error. */
+MtamRecordSet *mtam_records_parse_file(const char *path, char *err, int err_len);
+/* Parse the same text from memory (used by tests). */
+MtamRecordSet *mtam_records_parse_text(const char *text, long len, char *err, int err_len);
+/* Build from flattened arrays: offsets[n + 1] into the six per-event arrays. */
+MtamRecordSet *mtam_records_from_arrays(long n, const int64_t *offsets, const int32_t *user_id,
+                                        const int32_t *item, const int32_t *category, const float *time,
+                                        const float *timelast, const float *timenow,
+                                        const int32_t *position, const int32_t *target_id,
+                                        const int32_t *target_category, const float *target_time,
+                                        const int32_t *length, char *err, int err_len);
+void mtam_records_free(MtamRecordSet *rs);
+long mtam_records_count(const MtamRecordSet *rs);
+int mtam_records_max_length(const MtamRecordSet *rs);
+/* Copy record i out: lists into caller buffers of capacity cap; returns the list length or < 0. */
+int mtam_records_get(const MtamRecordSet *rs, long i, int cap, int32_t *user_id, int32_t *item,
+                     int32_t *category, float *time, float *timelast, float *timenow, int32_t *position,
+                     int32_t *target_id, int32_t *target_category, float *target_time, int32_t *length);
+
+/* Write records index[0 .. B) into `arena` (layout->words words, fully overwritten: pads are 0).
+ * L = length_of_user_history.  lr goes to arena[layout->lr] as a float.  Returns 0, or < 0 with a
+ * message naming the offending record (length > L, length < 2, id out of range). */
+int mtam_pack_batch(const MtamRecordSet *rs, const int64_t *index, int B, int L,
+                    const MtamArenaLayout *layout, const MtamTableRows *rows, float lr, int32_t *arena,
+                    char *err, int err_len);
+
+/* Fisher-Yates permutation of 0 .. n-1 from a 64-bit seed (splitmix64); the trainer reshuffles the
+ * training set every epoch (train_process.py:317). */
+void mtam_shuffle_index(int64_t *index, long n, uint64_t seed);
+
+int mtam_host_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTAM_HOST_H */

@@ -1,0 +1,229 @@
+"""Native batch feed: records held in libmtam_host.so, batches packed straight into pinned feed arenas.
+
+Drop-in for the trainer's ``for step_i, batch in DataInput(data, batch_size)`` loop
+(train_process.py:240,326): ``NativeDataInput`` yields ``(step_i, PackedBatch)`` with the same
+slicing (sequential, non-overlapping, short final batch); ``model.train`` / ``model.metrics_topK``
+accept a ``PackedBatch`` wherever they accept a list of record tuples.  Packing (pad to
+length_of_user_history with zeros at the end, id range checks -- what
+Embedding.make_feed_dic_new and TF's gather do, Embedding/Behavior_embedding_time_aware_attention.py:146-192)
+runs in C++ on a worker thread one batch ahead of the device.
+"""
+import ctypes
+import threading
+from collections import deque
+
+import numpy as np
+import torch
+
+from .. import _host_lib
+
+ERR_LEN = 512
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class RecordSet(object):
+    """Records in structure-of-arrays form inside the native library."""
+
+    def __init__(self, handle):
+        self._lib = _host_lib.load()
+        self._h = handle
+
+    @classmethod
+    def from_file(cls, path):
+        lib = _host_lib.load()
+        err = ctypes.create_string_buffer(ERR_LEN)
+        h = lib.mtam_records_parse_file(str(path).encode(), err, ERR_LEN)
+        if not h:
+            raise ValueError("%s: %s" % (path, err.value.decode()))
+        return cls(h)
+
+    @classmethod
+    def from_text(cls, text):
+        lib = _host_lib.load()
+        raw = text.encode()
+        err = ctypes.create_string_buffer(ERR_LEN)
+        h = lib.mtam_records_parse_text(raw, len(raw), err, ERR_LEN)
+        if not h:
+            raise ValueError(err.value.decode())
+        return cls(h)
+
+    @classmethod
+    def from_records(cls, records):
+        """From the reference's in-memory form: a list of 9-tuples."""
+        lib = _host_lib.load()
+        n = len(records)
+        lens = np.fromiter((len(r[1]) for r in records), dtype=np.int64, count=n)
+        for r in records:
+            if not (len(r[1]) == len(r[2]) == len(r[3]) == len(r[4]) == len(r[5]) == len(r[6])):
+                raise ValueError("the six lists of a record must have one length")
+        offsets = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        cat = lambda k, dt: np.ascontiguousarray(
+            np.concatenate([np.asarray(r[k], dtype=dt) for r in records]) if n else np.zeros(0, dt), dtype=dt)
+        item, category, position = cat(1, np.int32), cat(2, np.int32), cat(6, np.int32)
+        time, timelast, timenow = cat(3, np.float32), cat(4, np.float32), cat(5, np.float32)
+        col = lambda f, dt: np.ascontiguousarray(np.fromiter((f(r) for r in records), dtype=dt, count=n))
+        user = col(lambda r: r[0], np.int32)
+        tid, tcat = col(lambda r: r[7][0], np.int32), col(lambda r: r[7][1], np.int32)
+        ttime = col(lambda r: r[7][2], np.float32)
+        length = col(lambda r: r[8], np.int32)
+        err = ctypes.create_string_buffer(ERR_LEN)
+        h = lib.mtam_records_from_arrays(n, _ptr(offsets), _ptr(user), _ptr(item), _ptr(category), _ptr(time),
+                                         _ptr(timelast), _ptr(timenow), _ptr(position), _ptr(tid), _ptr(tcat),
+                                         _ptr(ttime), _ptr(length), err, ERR_LEN)
+        if not h:
+            raise ValueError(err.value.decode())
+        return cls(h)
+
+    def __len__(self):
+        return int(self._lib.mtam_records_count(self._h))
+
+    @property
+    def max_length(self):
+        return int(self._lib.mtam_records_max_length(self._h))
+
+    def record(self, i):
+        """Record i back as the reference's 9-tuple (times as floats)."""
+        cap = max(1, self.max_length)
+        ii = lambda: np.zeros(cap, np.int32)
+        ff = lambda: np.zeros(cap, np.float32)
+        item, category, position, time, timelast, timenow = ii(), ii(), ii(), ff(), ff(), ff()
+        u, tid, tcat, length = (ctypes.c_int32() for _ in range(4))
+        ttime = ctypes.c_float()
+        n = self._lib.mtam_records_get(self._h, i, cap, ctypes.byref(u), _ptr(item), _ptr(category), _ptr(time),
+                                       _ptr(timelast), _ptr(timenow), _ptr(position), ctypes.byref(tid),
+                                       ctypes.byref(tcat), ctypes.byref(ttime), ctypes.byref(length))
+        if n < 0:
+            raise IndexError(i)
+        return (u.value, item[:n].tolist(), category[:n].tolist(), time[:n].tolist(), timelast[:n].tolist(),
+                timenow[:n].tolist(), position[:n].tolist(), [tid.value, tcat.value, ttime.value], length.value)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.mtam_records_free(h)
+
+
+def shuffled_index(n, seed):
+    idx = np.zeros(n, np.int64)
+    _host_lib.load().mtam_shuffle_index(_ptr(idx), n, seed & 0xFFFFFFFFFFFFFFFF)
+    return idx
+
+
+class PackedBatch(object):
+    """One batch already laid out as the device feed arena (pinned host memory).  The arena belongs to
+    the packer's rotating pool (3 buffers): consume the batch before two further ones are packed."""
+
+    def __init__(self, arena, B, index, recordset, layout):
+        self.arena, self.B, self.index, self.recordset, self.layout = arena, B, index, recordset, layout
+
+    def __len__(self):
+        return self.B
+
+    def field(self, name):
+        """numpy view of one feed field of the packed arena (e.g. 'target_item_id')."""
+        o, n, shape, dt = self.layout[name]
+        v = self.arena[o:o + n]
+        return (v.view(torch.float32) if dt == torch.float32 else v).view(*shape).numpy()
+
+    def records(self):
+        return [self.recordset.record(int(i)) for i in self.index]
+
+
+class BatchPacker(object):
+    """Packs batches of a RecordSet for one model: owns the arena layout and the table row limits."""
+
+    def __init__(self, path, embedding, n_buffers=3):
+        """``path``: the model's TimeAwarePath, or just length_of_user_history (host-only use)."""
+        self._lib = _host_lib.load()
+        self.L = path if isinstance(path, int) else path.L
+        self.rows = _host_lib.TableRows(embedding.item_count + 3, embedding.category_count + 3,
+                                        embedding.position_count + 3, embedding.user_count + 3)
+        self.n_buffers = n_buffers
+        self._layouts = {}
+
+    def _layout(self, B):
+        if B not in self._layouts:
+            from ..Model.time_aware_path import arena_layout
+            offsets, words = arena_layout(B, self.L)
+            lay = _host_lib.ArenaLayout()
+            for k in ("user_id", "item_list", "category_list", "position_list", "target_item_id", "seq_length",
+                      "time_list", "timelast_list", "target_item_time", "lr"):
+                setattr(lay, k, offsets[k][0])
+            lay.words = words
+            pin = torch.cuda.is_available()
+            pool = deque((torch.zeros(words, dtype=torch.int32).pin_memory() if pin
+                          else torch.zeros(words, dtype=torch.int32)) for _ in range(self.n_buffers))
+            self._layouts[B] = (lay, offsets, pool)
+        return self._layouts[B]
+
+    def pack(self, recordset, index, lr=0.0):
+        index = np.ascontiguousarray(index, dtype=np.int64)
+        B = len(index)
+        lay, offsets, pool = self._layout(B)
+        arena = pool[0]
+        pool.rotate(-1)
+        err = ctypes.create_string_buffer(ERR_LEN)
+        rc = self._lib.mtam_pack_batch(recordset._h, _ptr(index), B, self.L, ctypes.byref(lay),
+                                       ctypes.byref(self.rows), float(lr), ctypes.c_void_p(arena.data_ptr()), err,
+                                       ERR_LEN)
+        if rc == -4:
+            raise IndexError(err.value.decode())
+        if rc != 0:
+            raise ValueError(err.value.decode())
+        return PackedBatch(arena, B, index, recordset, offsets)
+
+
+class NativeDataInput(object):
+    """``DataInput`` over a RecordSet: yields (step_i, PackedBatch), packing one batch ahead on a thread.
+    ``index`` (optional) is the epoch's record order, e.g. ``shuffled_index(len(rs), seed)``."""
+
+    def __init__(self, recordset, batch_size, packer, index=None, prefetch=True):
+        self.rs, self.batch_size, self.packer = recordset, int(batch_size), packer
+        n = len(recordset)
+        self.index = np.arange(n, dtype=np.int64) if index is None else np.ascontiguousarray(index, np.int64)
+        n = len(self.index)
+        self.epoch_size = (n + self.batch_size - 1) // self.batch_size
+        self.i = 0
+        self.prefetch = prefetch
+        self._pending = None
+
+    def __iter__(self):
+        return self
+
+    def _slice(self, i):
+        return self.index[i * self.batch_size:min((i + 1) * self.batch_size, len(self.index))]
+
+    def _start(self, i):
+        box = {}
+
+        def work():
+            try:
+                box["batch"] = self.packer.pack(self.rs, self._slice(i))
+            except Exception as e:                     # re-raised on the consumer side
+                box["error"] = e
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        return t, box
+
+    def __next__(self):
+        if self.i == self.epoch_size:
+            raise StopIteration
+        if not self.prefetch:
+            batch = self.packer.pack(self.rs, self._slice(self.i))
+        else:
+            if self._pending is None:
+                self._pending = self._start(self.i)
+            t, box = self._pending
+            t.join()
+            self._pending = self._start(self.i + 1) if self.i + 1 < self.epoch_size else None
+            if "error" in box:
+                raise box["error"]
+            batch = box["batch"]
+        self.i += 1
+        return self.i, batch
+
+    next = __next__

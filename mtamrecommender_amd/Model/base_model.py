@@ -171,12 +171,25 @@ class base_model(object):
             p.allreduce_fn(p, bt)
             self._run("train_up", bt, p.clip_and_apply)
 
-    def train(self, sess, batch_data, learning_rate, add_summary=False, global_step=0, epoch=0):
-        """One optimizer step on one batch -> (loss, summary) (reference :150-167)."""
+    def _load(self, batch_data, learning_rate=None):
+        """Feed -> device arena.  A list of record tuples goes through make_feed_dic_new (the
+        reference's route, :151); a PackedBatch (DataHandle/native_input.py) is already the arena."""
+        from ..DataHandle.native_input import PackedBatch
+        p = self.path
+        if isinstance(batch_data, PackedBatch):
+            bt = p.batch(batch_data.B)
+            lr_off = bt.offsets["lr"][0]
+            batch_data.arena[lr_off:lr_off + 1].view(torch.float32)[0] = \
+                float(np.float32(learning_rate)) if learning_rate is not None else 0.0
+            bt.arena.copy_(batch_data.arena, non_blocking=True)
+            return bt, batch_data.field("target_item_id")
         input_dic = self.embedding.make_feed_dic_new(batch_data=batch_data)
         self.embedding.validate_ids(input_dic)
-        p = self.path
-        bt = p.load_feed(input_dic, learning_rate)
+        return p.load_feed(input_dic, learning_rate), input_dic[self.embedding.target_item_id]
+
+    def train(self, sess, batch_data, learning_rate, add_summary=False, global_step=0, epoch=0):
+        """One optimizer step on one batch -> (loss, summary) (reference :150-167)."""
+        bt, _ = self._load(batch_data, learning_rate)
         self.step_train(bt)
         loss = bt.loss.cpu().numpy()
         summary = {"normalized Training Loss": float(loss[0]), "l2_norm": float(loss[1]),
@@ -186,13 +199,10 @@ class base_model(object):
     def metrics_topK(self, sess, batch_data, global_step, topk):
         """hr/ndcg @ 1, 5, 10, 30, 50 over the full catalog (reference :188-213;
         the ``topk`` argument is accepted and ignored there too)."""
-        input_dic = self.embedding.make_feed_dic_new(batch_data=batch_data)
-        self.embedding.validate_ids(input_dic)
         p = self.path
-        bt = p.load_feed(input_dic)
+        bt, result_item = self._load(batch_data)
         self._run("eval", bt, p.eval_kernels)
         top = bt.topk_idx.cpu().numpy()
-        result_item = input_dic[self.embedding.target_item_id]
         length = len(batch_data)
         out = []
         for k in (1, 5, 10, 30, 50):
@@ -203,13 +213,11 @@ class base_model(object):
 
     def recall_at(self, sess, batch_data, k=20):
         """Recall@k per batch (BASELINE.json's metric; the reference never computes K=20)."""
-        input_dic = self.embedding.make_feed_dic_new(batch_data=batch_data)
         p = self.path
-        bt = p.load_feed(input_dic)
+        bt, tgt = self._load(batch_data)
         self._run("eval", bt, p.eval_kernels)
         top = bt.topk_idx.cpu().numpy()[:, :k]
-        tgt = input_dic[self.embedding.target_item_id]
-        return float((top == tgt[:, None]).any(axis=1).mean())
+        return float((top == np.asarray(tgt)[:, None]).any(axis=1).mean())
 
     def calculate_topK(self, k, indices_result, result_item, global_step, length):
         total_count = 0

@@ -39,6 +39,22 @@ def _chunks(seq, n):
         yield seq[i:i + n]
 
 
+def arena_layout(B, L):
+    """Word offsets of the feed fields inside one int32 arena: name -> (offset, count, shape, dtype),
+    plus the arena size.  Every field starts on a 16-byte boundary."""
+    fields = [("user_id", (B,), torch.int32), ("item_list", (B, L), torch.int32),
+              ("category_list", (B, L), torch.int32), ("position_list", (B, L), torch.int32),
+              ("target_item_id", (B,), torch.int32), ("seq_length", (B,), torch.int32),
+              ("time_list", (B, L), torch.float32), ("timelast_list", (B, L), torch.float32),
+              ("target_item_time", (B,), torch.float32), ("lr", (4,), torch.float32)]
+    offsets, o = {}, 0
+    for name, shape, dt in fields:
+        n = int(np.prod(shape))
+        offsets[name] = (o, n, shape, dt)
+        o += (n + 3) // 4 * 4
+    return offsets, o
+
+
 class _Inline(object):
     def __enter__(self):
         return self
@@ -58,16 +74,7 @@ class _Batch(object):
         self.B, self.R = B, R
         # feed: ONE arena of 4-byte words at a fixed address (ids, times, learning rate), so that a
         # step needs one host->device (or device->device) copy and can be replayed from a hipGraph.
-        fields = [("user_id", (B,), torch.int32), ("item_list", (B, L), torch.int32),
-                  ("category_list", (B, L), torch.int32), ("position_list", (B, L), torch.int32),
-                  ("target_item_id", (B,), torch.int32), ("seq_length", (B,), torch.int32),
-                  ("time_list", (B, L), torch.float32), ("timelast_list", (B, L), torch.float32),
-                  ("target_item_time", (B,), torch.float32), ("lr", (4,), torch.float32)]
-        self.offsets, o = {}, 0
-        for name, shape, dt in fields:
-            n = int(np.prod(shape))
-            self.offsets[name] = (o, n, shape, dt)
-            o += (n + 3) // 4 * 4
+        self.offsets, o = arena_layout(B, L)
         self.arena = torch.zeros(o, dtype=torch.int32, device=dev)
         self.host_arena = torch.zeros(o, dtype=torch.int32).pin_memory()
         self.feed = {name: self._view(self.arena, name) for name in self.offsets}

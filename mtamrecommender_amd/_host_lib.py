@@ -1,0 +1,53 @@
+"""ctypes loader of libmtam_host.so (include/mtam_host.h): record parsing and batch packing."""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_long, c_uint64, c_void_p
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmtam_host.so")
+P = c_void_p
+
+
+class ArenaLayout(ctypes.Structure):
+    _fields_ = [(k, c_int) for k in ("user_id", "item_list", "category_list", "position_list", "target_item_id",
+                                     "seq_length", "time_list", "timelast_list", "target_item_time", "lr", "words")]
+
+
+class TableRows(ctypes.Structure):
+    _fields_ = [(k, c_int) for k in ("item_rows", "category_rows", "position_rows", "user_rows")]
+
+
+SIGNATURES = {
+    "mtam_records_parse_file": (P, [c_char_p, c_char_p, c_int]),
+    "mtam_records_parse_text": (P, [c_char_p, c_long, c_char_p, c_int]),
+    "mtam_records_from_arrays": (P, [c_long, P, P, P, P, P, P, P, P, P, P, P, P, c_char_p, c_int]),
+    "mtam_records_free": (None, [P]),
+    "mtam_records_count": (c_long, [P]),
+    "mtam_records_max_length": (c_int, [P]),
+    "mtam_records_get": (c_int, [P, c_long, c_int, P, P, P, P, P, P, P, P, P, P, P]),
+    "mtam_pack_batch": (c_int, [P, P, c_int, c_int, P, P, c_float, P, c_char_p, c_int]),
+    "mtam_shuffle_index": (None, [P, c_long, c_uint64]),
+    "mtam_host_version": (c_int, []),
+}
+
+_lib = None
+
+
+class MtamHostError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise if it was not built (no silent Python fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MtamHostError("libmtam_host.so not found at %s -- build it with `make -C mtamrecommender_amd/csrc`"
+                            % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

@@ -134,6 +134,9 @@ class model_parameter(object):
         # Additions of this build (not reference flags).
         f.DEFINE_boolean('tf_compat_global_norm', True,
                          'clip with TF1.14 IndexedSlices norm (SURVEY.md App D-5)')
+        f.DEFINE_boolean('native_input', True,
+                         'pack batches with libmtam_host.so on a worker thread (DataHandle/native_input.py) instead of '
+                         'make_feed_dic_new per step')
         f.DEFINE_boolean('swallow_step_errors', False,
                          'log-and-continue on a failed step like train_process.py:369-371')
 

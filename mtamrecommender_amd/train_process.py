@@ -110,9 +110,36 @@ class Train_main_process(object):
                                       "self-attention model only)" % self.FLAGS.experiment_type)
         return self.model
 
+    # ------------------------------------------------------------------- feeds
+    def _init_feeds(self):
+        """Native feed (FLAGS.native_input): records move into libmtam_host.so once; batches are padded and
+        range-checked in C++ one step ahead of the device.  Otherwise the reference's route: Python lists
+        through DataInput and make_feed_dic_new."""
+        self._native = bool(getattr(self.FLAGS, "native_input", False))
+        if self._native:
+            from .DataHandle.native_input import BatchPacker, RecordSet
+            self._packer = BatchPacker(self.model.path, self.emb)
+            self._train_rs = RecordSet.from_records(self.train_set)
+            self._test_rs = RecordSet.from_records(self.test_set)
+            self._order = list(range(len(self.train_set)))
+
+    def _train_batches(self):
+        if not self._native:
+            random.shuffle(self.train_set)
+            return DataInput(self.train_set, self.FLAGS.train_batch_size)
+        from .DataHandle.native_input import NativeDataInput
+        random.shuffle(self._order)          # the same permutation random.shuffle(train_set) would apply
+        return NativeDataInput(self._train_rs, self.FLAGS.train_batch_size, self._packer, index=self._order)
+
+    def _test_batches(self):
+        if not self._native:
+            return DataInput(self.test_set, self.FLAGS.test_batch_size)
+        from .DataHandle.native_input import NativeDataInput
+        return NativeDataInput(self._test_rs, self.FLAGS.test_batch_size, self._packer)
+
     def eval_topk(self):
         per_batch = []
-        for _, batch_data in DataInput(self.test_set, self.FLAGS.test_batch_size):
+        for _, batch_data in self._test_batches():
             per_batch.append(self.model.metrics_topK(sess=self.sess, batch_data=batch_data,
                                                      global_step=self.global_step, topk=self.FLAGS.top_k))
         avg = average_metrics(per_batch)
@@ -131,6 +158,7 @@ class Train_main_process(object):
     def train(self, max_steps=None):
         start_time = time.time()
         self.build_model()
+        self._init_feeds()
         self.logger.info('Init finish.\tCost time: %.2fs' % (time.time() - start_time))
         test_start = time.time()
         self.eval_topk()
@@ -139,11 +167,11 @@ class Train_main_process(object):
                          % (self.FLAGS.max_epochs, self.FLAGS.train_batch_size))
         start_time, avg_loss, step_loss = time.time(), 0.0, float("nan")
         for epoch in range(self.FLAGS.max_epochs):
-            random.shuffle(self.train_set)
+            batches = self._train_batches()
             self.logger.info('tain_set:%d' % len(self.train_set))
             epoch_start_time = time.time()
             learning_rate = self.FLAGS.learning_rate
-            for step_i, train_batch_data in DataInput(self.train_set, self.FLAGS.train_batch_size):
+            for step_i, train_batch_data in batches:
                 try:
                     learning_rate = next_learning_rate(learning_rate, self.FLAGS.learning_rate,
                                                        self.FLAGS.decay_rate, self.global_step)

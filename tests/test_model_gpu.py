@@ -276,3 +276,37 @@ def test_other_optimizers_track_the_oracle(hip_lib, tmp_path, optimizer):
             assert d.max() <= 3 * 3.2 * lr * 2 and (d > 2e-5).mean() < 2e-3, name
         else:
             assert d.max() <= 2e-4 * scale, name
+
+
+def test_native_feed_equals_python_feed(hip_lib, tmp_path):
+    """libmtam_host.so's packed arenas drive the same steps as make_feed_dic_new (bit-equal losses and
+    metrics), through train / metrics_topK / recall_at and through the trainer's batch loop."""
+    from mtamrecommender_amd.DataHandle.native_input import BatchPacker, NativeDataInput, RecordSet
+    B, L = 16, 20
+    model_a, FLAGS, records = build(tmp_path, 3 * B, L, 1, 1)
+    model_b, _, _ = build(tmp_path, 3 * B, L, 1, 1)
+    rs = RecordSet.from_records(records)
+    packer = BatchPacker(model_b.path, model_b.embedding)
+    for step, packed in NativeDataInput(rs, B, packer):
+        batch = records[(step - 1) * B:step * B]
+        la, _ = model_a.train(model_a.sess, batch, 1e-3)
+        lb, _ = model_b.train(model_b.sess, packed, 1e-3)
+        assert la == lb, step
+    packed = packer.pack(rs, list(range(B)))
+    assert model_a.metrics_topK(model_a.sess, records[:B], 0, 20) == model_b.metrics_topK(model_b.sess, packed, 0, 20)
+    assert model_a.recall_at(model_a.sess, records[:B], 20) == model_b.recall_at(model_b.sess, packed, 20)
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_trainer_loop_runs_on_both_feeds(hip_lib, tmp_path, native):
+    from mtamrecommender_amd.data.synthetic import SyntheticCatalog, make_records
+    from mtamrecommender_amd.train_process import Train_main_process
+    cat = SyntheticCatalog(120, 9, 30, seed=2)
+    train, test = make_records(cat, 200, 20, seed=3), make_records(cat, 40, 20, seed=4)
+    argv = ["--length_of_user_history", "20", "--train_batch_size", "32", "--test_batch_size", "16",
+            "--max_epochs", "1", "--eval_freq", "4", "--checkpoint_path_dir", str(tmp_path),
+            "--native_input", "true" if native else "false"]
+    t = Train_main_process("MTAMb1_movielen", argv, train_set=train, test_set=test,
+                           counts=dict(user_count=30, item_count=120, category_count=9))
+    t.train(max_steps=6)
+    assert t.global_step == 6
