@@ -77,6 +77,7 @@ class base_model(object):
         self.logger = create_log().logger
         self.path = None            # TimeAwarePath, built by build_model()
         self.use_graph = os.environ.get("MTAM_HIP_GRAPH", "1") != "0"
+        self._dp_mode = os.environ.get("MTAM_DP_GRAPH", "fused")
         self._graphs = {}
 
     # ------------------------------------------------------------ life cycle
@@ -141,7 +142,7 @@ class base_model(object):
         self.logger.info('model restored from %s' % path)
 
     # ------------------------------------------------------------------ step
-    def _run(self, kind, bt, fn):
+    def _run(self, kind, bt, fn, **graph_kw):
         """Eager on first use of a batch size, then one hipGraph replay per step."""
         if not self.use_graph:
             fn(bt)
@@ -155,21 +156,35 @@ class base_model(object):
                 return
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):                    # records the launches, executes nothing
+            with torch.cuda.graph(g, **graph_kw):        # records the launches, executes nothing
                 fn(bt)
             self._graphs[key] = g
         g.replay()
 
     def step_train(self, bt):
-        """One training step on the feed already in ``bt.arena``.  With data parallelism
-        the RCCL exchange runs between two captured graphs."""
+        """One training step on the feed already in ``bt.arena``.
+
+        Data parallel: the RCCL all-reduce sits between backward and update.  ``MTAM_DP_GRAPH``:
+        ``fused`` (default) captures forward, backward, the collective and the update into ONE
+        hipGraph (RCCL enqueues into the capturing stream; thread-local capture mode keeps the
+        process group's watchdog thread from invalidating it); if that capture raises, or with
+        ``split``, the step is two graphs with the collective launched between them."""
         p = self.path
         if p.allreduce_fn is None:
             self._run("train", bt, p.train_kernels)
-        else:
-            self._run("train_fb", bt, p.forward_backward_kernels)
-            p.allreduce_fn(p, bt)
-            self._run("train_up", bt, p.clip_and_apply)
+            return
+        if self._dp_mode == "fused":
+            try:
+                self._run("train_dp", bt, p.train_kernels, capture_error_mode="thread_local")
+                return
+            except Exception as e:                       # capture of the collective not supported here
+                self.logger.info("fused data-parallel graph unavailable (%s): using split graphs" % (e,))
+                self._dp_mode = "split"
+                self._graphs.pop(("train_dp", bt.B), None)
+                torch.cuda.synchronize()
+        self._run("train_fb", bt, p.forward_backward_kernels)
+        p.allreduce_fn(p, bt)
+        self._run("train_up", bt, p.clip_and_apply)
 
     def _load(self, batch_data, learning_rate=None):
         """Feed -> device arena.  A list of record tuples goes through make_feed_dic_new (the
