@@ -190,6 +190,11 @@ class NativeDataInput(object):
         self.i = 0
         self.prefetch = prefetch
         self._pending = None
+        # Pinned arenas are allocated HERE, on the caller's thread: the worker thread must not make HIP
+        # calls (hipHostMalloc while the main thread captures a hipGraph invalidates the capture).
+        for size in {min(self.batch_size, n), n % self.batch_size}:
+            if size > 0:
+                packer._layout(size)
 
     def __iter__(self):
         return self
