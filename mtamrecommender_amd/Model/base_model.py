@@ -141,6 +141,56 @@ class base_model(object):
             p.load_optimizer_state(state["adam"])
         self.logger.info('model restored from %s' % path)
 
+    # ------------------------------------------------- TF-named interchange
+    def export_tf_npz(self, file_path):
+        """Every variable a TF 1.14 ``tf.train.Saver`` would hold for this graph, keyed by its TF name
+        (SURVEY.md App B): trainable variables, the never-updated ones, and Adam's slots
+        ``<name>/Adam`` (m), ``<name>/Adam_1`` (v), ``beta1_power``, ``beta2_power``.  The other
+        direction of ``import_tf_npz``; a reference checkpoint becomes such a file with
+        ``{n: r.get_tensor(n) for n in r.get_variable_to_shape_map()}`` on a machine that has TF."""
+        p = self.path
+        out = dict(self.get_variables())
+        if p.optimizer == "adam":
+            m, v = p.layout.unpack(p.m.detach().cpu().numpy()), p.layout.unpack(p.v.detach().cpu().numpy())
+            for k in m:
+                out[k + "/Adam"], out[k + "/Adam_1"] = m[k], v[k]
+            for k in p.tables:
+                out["embedding_layer/%s/Adam" % k] = p.tm[k].detach().cpu().numpy()
+                out["embedding_layer/%s/Adam_1" % k] = p.tv[k].detach().cpu().numpy()
+            st = p.adam_state.cpu().numpy()
+            out["beta1_power"], out["beta2_power"] = np.float32(st[4]), np.float32(st[5])
+        np.savez(file_path, **{k.replace("/", "__"): v for k, v in out.items()})
+        return sorted(out)
+
+    def import_tf_npz(self, file_path):
+        """Load variables (and, when present, Adam slots) from an ``export_tf_npz``-style file.  Keys may
+        carry TF's ``:0`` suffix; shapes are checked; a trainable variable missing from the file raises."""
+        p = self.path
+        raw = np.load(file_path, allow_pickle=False)
+        arrays = {k.replace("__", "/").split(":")[0]: raw[k] for k in raw.files}
+        mine = self.get_variables()
+        for k, v in mine.items():
+            if k not in arrays:
+                if k in self.dead_variables:
+                    continue
+                raise KeyError("variable %s missing from %s" % (k, file_path))
+            if tuple(arrays[k].shape) != tuple(v.shape):
+                raise ValueError("%s: shape %s in the file, %s in the model" % (k, arrays[k].shape, v.shape))
+        self.set_variables({k: arrays[k] for k in mine if k in arrays})
+        if p.optimizer == "adam" and "beta1_power" in arrays:
+            dense = p.dense_tf()
+            m = {k: arrays.get(k + "/Adam", np.zeros_like(v)) for k, v in dense.items()}
+            v_ = {k: arrays.get(k + "/Adam_1", np.zeros_like(v)) for k, v in dense.items()}
+            p.m.copy_(torch.from_numpy(p.layout.pack(m)))
+            p.v.copy_(torch.from_numpy(p.layout.pack(v_)))
+            for k in p.tables:
+                if "embedding_layer/%s/Adam" % k in arrays:
+                    p.tm[k].copy_(torch.from_numpy(np.ascontiguousarray(arrays["embedding_layer/%s/Adam" % k])))
+                    p.tv[k].copy_(torch.from_numpy(np.ascontiguousarray(arrays["embedding_layer/%s/Adam_1" % k])))
+            st = p.adam_state.cpu()
+            st[4], st[5] = float(arrays["beta1_power"]), float(arrays["beta2_power"])
+            p.adam_state.copy_(st)
+
     # ------------------------------------------------------------------ step
     def _run(self, kind, bt, fn, **graph_kw):
         """Eager on first use of a batch size, then one hipGraph replay per step."""
