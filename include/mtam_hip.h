@@ -59,6 +59,9 @@ const char *mtam_arch(void);     /* "gfx950" */
  *   MTAM_EPI_ATOMIC      atomicAdd(C, acc)   (split_k >= 1 slices of K)
  *   MTAM_EPI_ACCUM2_MASK C += acc + add2[m,n]; aux_out = (aux_in[m,n] > 0) ? C : 0
  *                        (add2 is passed in the `bias` argument as an [M, ld_aux] matrix)
+ *   MTAM_EPI_STORE_SQ    C = acc; aux_out[4 * tile + wave] = sum of acc^2 over the wave's in-range
+ *                        32x32 quadrant: mtam_gemm_sq_partials(M, N) floats whose sum is ||C||^2
+ *                        (the dense item gradient's share of tf.global_norm, Model/base_model.py:294)
  * aux_in / aux_out share ld_aux.  split_k > 1 is only valid with ATOMIC.
  */
 enum {
@@ -69,8 +72,10 @@ enum {
   MTAM_EPI_ACCUM = 4,
   MTAM_EPI_ACCUM_MASK = 5,
   MTAM_EPI_ATOMIC = 6,
-  MTAM_EPI_ACCUM2_MASK = 7
+  MTAM_EPI_ACCUM2_MASK = 7,
+  MTAM_EPI_STORE_SQ = 8
 };
+int mtam_gemm_sq_partials(int M, int N);
 int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
                   const float *A, int lda, const float *B, int ldb,
                   float *C, int ldc, int epilogue, const float *bias,
@@ -129,6 +134,19 @@ int mtam_emb_gather_fwd(const float *item_table, int item_rows,
                         int B, int L, int with_user,
                         float *item_cat_out, float *pos_out, float *user_out,
                         float *l2_partial, void *stream);
+/* The same launch, additionally clearing two float ranges (n_a, n_b floats; 16-byte aligned, multiples
+ * of 4): the training step's gradient accumulators, zeroed by its first kernel instead of two fill
+ * launches (tf.gradients starts from zero accumulators, Model/base_model.py:292). */
+int mtam_emb_gather_fwd_clear(const float *item_table, int item_rows,
+                              const float *cat_table, int cat_rows,
+                              const float *pos_table, int pos_rows,
+                              const float *user_table, int user_rows,
+                              const int32_t *item_ids, const int32_t *cat_ids,
+                              const int32_t *pos_ids, const int32_t *user_ids,
+                              int B, int L, int with_user,
+                              float *item_cat_out, float *pos_out, float *user_out,
+                              float *l2_partial, float *clear_a, size_t n_a, float *clear_b, size_t n_b,
+                              void *stream);
 
 /* ---------------------------------------------------- embedding scatter-add
  * Gradient of the four lookups (tf.gradients through embedding_lookup,

@@ -53,7 +53,9 @@ class SelfAttentionPath(TimeAwarePath):
         fd, T = bt.feed, self.tables
         ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
                            fd["category_list"], fd["position_list"], fd["user_id"], B, L, 0,
-                           bt.ic, bt.pos, bt.user, bt.l2_partial)
+                           bt.ic, bt.pos, bt.user, bt.l2_partial,
+                           # a training step's first kernel also clears its gradient accumulators
+                           clear=(self.zero_prefix, bt.d_pred.view(-1)) if training else ())
         ops.gemm(bt.ic, self.seg("dense4emb/w"), bt.x, epilogue=ops.EPI_RELU_ADD, aux_in=bt.pos, aux_out=bt.zr)
         for i in range(NB):
             enc, qkv, qt = bt.enc[i], bt.qkv[i], bt.qt[i]
@@ -86,11 +88,11 @@ class SelfAttentionPath(TimeAwarePath):
         gseg = lambda name: self.layout.view(G, name)
         part = bt.norm_partial
         sr = max(1, min(16, R // 256))
-        self.zero_prefix.zero_()
-        bt.d_pred.zero_()
-        ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
         if self.tf_compat:
-            ops.sqnorm_partial(self.g_tab["item"], self.g_tab["item"].numel(), part[self.nb_dense:])
+            ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True, epilogue=ops.EPI_STORE_SQ,
+                     aux_out=part[self.nb_dense:])
+        else:
+            ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
         split_v = max(1, min(64, (self.item_rows + 127) // 128))
         ops.gemm(bt.logits, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v)
         ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_long, gseg("head/ln"))

@@ -162,7 +162,8 @@ class TimeAwarePath(object):
             self.flat_m.fill_(1.0)      # the "rms" slot starts at one [TF1.14 RMSPropOptimizer._create_slots]
         self.zero_prefix = self.flat_g[:self.tab_off["item"]]
         self.nb_dense = ops.sqnorm_blocks(self.n_dense)
-        self.nb_item = ops.sqnorm_blocks(self.tables["item"].numel())
+        # the dense item gradient's squared norm comes out of its GEMM's epilogue (one partial per wave)
+        self.nb_item = ops.gemm_sq_partials(self.item_rows, D)
         self.nb_all = max(ops.sqnorm_blocks(self.n_total), self.nb_dense + self.nb_item)
         self.scale = z(2)
         self.ticket = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -231,7 +232,9 @@ class TimeAwarePath(object):
         fd, T = bt.feed, self.tables
         ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
                            fd["category_list"], fd["position_list"], fd["user_id"], B, L, 1,
-                           bt.ic, bt.pos, bt.user, bt.l2_partial)
+                           bt.ic, bt.pos, bt.user, bt.l2_partial,
+                           # a training step's first kernel also clears its gradient accumulators
+                           clear=(self.zero_prefix, bt.d_pred.view(-1)) if training else ())
         ops.gemm(bt.ic, self.seg("dense4emb/w"), bt.x, epilogue=ops.EPI_RELU_ADD, aux_in=bt.pos, aux_out=bt.zr)
         with self._fork(0):          # keys/values of every block: independent of the GRU
             ops.gemm(bt.x, self.seg("kv/w"), bt.kv, epilogue=ops.EPI_BIAS_RELU, bias=self.seg("kv/b"))
@@ -268,14 +271,14 @@ class TimeAwarePath(object):
         sr = max(1, min(16, R // 256))
         prob = lambda A, lda, Bm, ldb, name, M, N, K, s: dict(A=A, lda=lda, B=Bm, ldb=ldb, C=gseg(name),
                                                               ldc=N, M=M, N=N, K=K, split_k=s)
-        self.zero_prefix.zero_()
-        bt.d_pred.zero_()
         # Side 1: dense item gradient dE = G^T pred (every row) and its share of the TF global norm.
         # Only the scatter at the very end needs it.
         with self._fork(1):
-            ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
             if self.tf_compat:
-                ops.sqnorm_partial(self.g_tab["item"], self.g_tab["item"].numel(), part[self.nb_dense:])
+                ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True, epilogue=ops.EPI_STORE_SQ,
+                         aux_out=part[self.nb_dense:])
+            else:
+                ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
         # Main chain: d_pred = G E -> head LN -> decoder blocks (last to first)
         split_v = max(1, min(64, (self.item_rows + 127) // 128))
         ops.gemm(bt.logits, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v)

@@ -18,6 +18,7 @@ SIGNATURES = {
     "mtam_last_error": (ctypes.c_char_p, []),
     "mtam_version": (c_int, []),
     "mtam_arch": (ctypes.c_char_p, []),
+    "mtam_gemm_sq_partials": (c_int, [c_int, c_int]),
     "mtam_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int,
                               P, P, P, c_int, c_int, P]),
     "mtam_gemm_f32_batched": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, ctypes.c_long, ctypes.c_long,
@@ -27,6 +28,8 @@ SIGNATURES = {
     "mtam_emb_gather_partials": (c_int, [c_int, c_int]),
     "mtam_emb_gather_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
                                     P, P, P, P, P]),
+    "mtam_emb_gather_fwd_clear": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
+                                          P, P, P, P, P, c_size_t, P, c_size_t, P]),
     "mtam_emb_scatter_partials": (c_int, [c_int, c_int]),
     "mtam_emb_scatter_add_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
                                          P, c_int, P, c_int, P, c_int, P, c_int, P, P]),

@@ -24,6 +24,10 @@ struct GatherArgs {
   const int32_t *item_ids, *cat_ids, *pos_ids, *user_ids;
   int B, L, with_user;
   float *ic_out, *pos_out, *user_out, *l2_partial;
+  // optional: two float ranges to clear (the step's gradient accumulators), spread over the grid.
+  // The gather is the first kernel of a training step and is latency-bound, so the stores ride along.
+  float4 *clear_a, *clear_b;
+  size_t n_a4, n_b4;
 };
 
 // Slot s < R      : row r = s of the [item | category] concat, one wave (halves = item, category).
@@ -79,6 +83,12 @@ __global__ __launch_bounds__(256) void emb_gather_kernel(GatherArgs p) {
   }
   sq = wave_sum(sq);
   if (lane == 0) p.l2_partial[wave_id] = sq;
+  if (p.n_a4 | p.n_b4) {
+    const size_t stride = (size_t)gridDim.x * 256, g0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = g0; i < p.n_a4; i += stride) p.clear_a[i] = z;
+    for (size_t i = g0; i < p.n_b4; i += stride) p.clear_b[i] = z;
+  }
 }
 
 constexpr int WPB = 16;                      // waves (= norm partials) per scatter workgroup
@@ -328,6 +338,22 @@ extern "C" int mtam_emb_gather_fwd(const float *item_table, int item_rows, const
                                    const int32_t *user_ids, int B, int L, int with_user,
                                    float *item_cat_out, float *pos_out, float *user_out,
                                    float *l2_partial, void *stream) {
+  return mtam_emb_gather_fwd_clear(item_table, item_rows, cat_table, cat_rows, pos_table, pos_rows, user_table,
+                                   user_rows, item_ids, cat_ids, pos_ids, user_ids, B, L, with_user, item_cat_out,
+                                   pos_out, user_out, l2_partial, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int mtam_emb_gather_fwd_clear(const float *item_table, int item_rows, const float *cat_table,
+                                         int cat_rows, const float *pos_table, int pos_rows,
+                                         const float *user_table, int user_rows, const int32_t *item_ids,
+                                         const int32_t *cat_ids, const int32_t *pos_ids,
+                                         const int32_t *user_ids, int B, int L, int with_user,
+                                         float *item_cat_out, float *pos_out, float *user_out,
+                                         float *l2_partial, float *clear_a, size_t n_a, float *clear_b,
+                                         size_t n_b, void *stream) {
+  MTAM_CHECK_ARG((n_a == 0 || (clear_a && mtam_aligned16(clear_a) && n_a % 4 == 0)) &&
+                     (n_b == 0 || (clear_b && mtam_aligned16(clear_b) && n_b % 4 == 0)),
+                 "emb_gather: clear ranges must be 16-byte aligned multiples of 4 floats");
   MTAM_CHECK_ARG(B > 0 && L > 0, "emb_gather: B and L must be positive");
   MTAM_CHECK_ARG((long)B * L * 3 + B < 0x3fffffffL, "emb_gather: batch too large");
   MTAM_CHECK_ARG(item_table && cat_table && pos_table && user_table, "emb_gather: null table");
@@ -340,7 +366,8 @@ extern "C" int mtam_emb_gather_fwd(const float *item_table, int item_rows, const
                  "emb_gather: tables and outputs must be 16-byte aligned");
   GatherArgs a{item_table, cat_table, pos_table, user_table, item_rows, cat_rows, pos_rows, user_rows,
                item_ids, cat_ids, pos_ids, user_ids, B, L, with_user,
-               item_cat_out, pos_out, user_out, l2_partial};
+               item_cat_out, pos_out, user_out, l2_partial,
+               reinterpret_cast<float4 *>(clear_a), reinterpret_cast<float4 *>(clear_b), n_a / 4, n_b / 4};
   const int blocks = mtam_emb_gather_partials(B, L) / 4;
   hipLaunchKernelGGL(emb_gather_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("emb_gather");

@@ -126,7 +126,8 @@ constexpr int TILE_FLOATS = BK * LDM;   // one operand tile in LDS
 // trip per row (16 rows: 12,000 cycles for RELU_ADD, 36,000 for ACCUM2_MASK, tools/gemm_lab.hip).
 template <int EPI>
 __device__ __forceinline__ void store_acc(const GemmArgs &p, const f32x16 &acc, int row0, int gn, int lane) {
-  if (gn >= p.N) return;
+  float sq = 0.f;
+  if (EPI != MTAM_EPI_STORE_SQ && gn >= p.N) return;
   constexpr bool READ_C = EPI == MTAM_EPI_ACCUM || EPI == MTAM_EPI_ACCUM_MASK || EPI == MTAM_EPI_ACCUM2_MASK;
   constexpr bool READ_AUX = EPI == MTAM_EPI_RELU_ADD || EPI == MTAM_EPI_ACCUM_MASK || EPI == MTAM_EPI_ACCUM2_MASK;
   constexpr bool READ_BIAS2 = EPI == MTAM_EPI_ACCUM2_MASK;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void store_acc(const GemmArgs &p, const f32x16 &acc, 
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int gm = rbase + (r & 3) + 8 * (r >> 2);
-    if (gm >= p.M) continue;
+    if (gm >= p.M || gn >= p.N) continue;
     float v = acc[r];
     float *c = p.C + (size_t)gm * p.ldc + gn;
     const size_t o = (size_t)gm * p.ld_aux + gn;
@@ -168,9 +169,16 @@ __device__ __forceinline__ void store_acc(const GemmArgs &p, const f32x16 &acc, 
       v += cv[r] + bv[r];
       *c = v;
       p.aux_out[o] = (av[r] > 0.f) ? v : 0.f;
+    } else if (EPI == MTAM_EPI_STORE_SQ) {
+      *c = v;
+      sq += v * v;
     } else {  // MTAM_EPI_ATOMIC
       atomicAdd(c, v);
     }
+  }
+  if (EPI == MTAM_EPI_STORE_SQ) {
+    sq = wave_sum(sq);
+    if ((lane & 63) == 0) p.aux_out[4 * (size_t)blockIdx.x + (threadIdx.x >> 6)] = sq;
   }
 }
 
@@ -344,11 +352,14 @@ void launch_epi(int epi, dim3 grid, hipStream_t s, const GemmArgs &a) {
     case MTAM_EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ACCUM>), grid, dim3(256), 0, s, a); break;
     case MTAM_EPI_ACCUM_MASK: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ACCUM_MASK>), grid, dim3(256), 0, s, a); break;
     case MTAM_EPI_ACCUM2_MASK: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ACCUM2_MASK>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_STORE_SQ: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_STORE_SQ>), grid, dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ATOMIC>), grid, dim3(256), 0, s, a); break;
   }
 }
 
 }  // namespace
+
+extern "C" int mtam_gemm_sq_partials(int M, int N) { return 4 * ((M + BM - 1) / BM) * ((N + BN - 1) / BN); }
 
 extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                              const float *B, int ldb, float *C, int ldc, int epilogue,
@@ -356,7 +367,8 @@ extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, cons
                              int split_k, void *stream) {
   MTAM_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive (got %d %d %d)", M, N, K);
   MTAM_CHECK_ARG(A && B && C, "gemm: null operand");
-  MTAM_CHECK_ARG(epilogue >= MTAM_EPI_STORE && epilogue <= MTAM_EPI_ACCUM2_MASK, "gemm: bad epilogue %d", epilogue);
+  MTAM_CHECK_ARG(epilogue >= MTAM_EPI_STORE && epilogue <= MTAM_EPI_STORE_SQ, "gemm: bad epilogue %d", epilogue);
+  if (epilogue == MTAM_EPI_STORE_SQ) MTAM_CHECK_ARG(aux_out != nullptr, "gemm: STORE_SQ needs aux_out for the partial sums");
   MTAM_CHECK_ARG(lda >= (trans_a ? M : K), "gemm: lda %d too small", lda);
   MTAM_CHECK_ARG(ldb >= (trans_b ? K : N), "gemm: ldb %d too small", ldb);
   MTAM_CHECK_ARG(ldc >= N, "gemm: ldc %d too small", ldc);

@@ -87,16 +87,16 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
     for (int jb = hw; jb < L; jb += 8 * KB) {
       float4 kq[KB], xq[KB];
       float tk[KB], tp[KB][5];
+      // unconditional loads at a clamped row (padded keys are valid memory and are masked below):
+      // inside `if (j < sl)` every key's loads were waited for before the next key's were issued
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
-        const int j = jb + 8 * i;
-        if (j < sl) {
-          kq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.k_off + 4 * li]);
-          xq[i] = *reinterpret_cast<const float4 *>(&p.x[(row0 + j) * D + 4 * li]);
-          tk[i] = p.t_keys[row0 + j];
+        const int jc = min(jb + 8 * i, L - 1);
+        kq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.k_off + 4 * li]);
+        xq[i] = *reinterpret_cast<const float4 *>(&p.x[(row0 + jc) * D + 4 * li]);
+        tk[i] = p.t_keys[row0 + jc];
 #pragma unroll
-          for (int q = 0; q < 5; ++q) tp[i][q] = p.tparams[q * L + j];
-        }
+        for (int q = 0; q < 5; ++q) tp[i][q] = p.tparams[q * L + jc];
       }
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
     for (int jb = j0; jb < j1; jb += 8) {
       float vv[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) vv[i] = (jb + i < j1) ? p.kv[(row0 + jb + i) * p.ld_kv + p.v_off + c] : 0.f;
+      for (int i = 0; i < 8; ++i) vv[i] = p.kv[(row0 + min(jb + i, L - 1)) * p.ld_kv + p.v_off + c];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (jb + i < j1) o = fmaf(sc_s[h][jb + i], vv[i], o);
@@ -272,10 +272,8 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     for (int jb = hw; jb < L; jb += 8 * KB) {
       float4 vq[KB];
 #pragma unroll
-      for (int i = 0; i < KB; ++i) {
-        const int j = jb + 8 * i;
-        if (j < sl) vq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.v_off + 4 * li]);
-      }
+      for (int i = 0; i < KB; ++i)      // unconditional, clamped row (see the forward kernel)
+        vq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + min(jb + 8 * i, L - 1)) * p.ld_kv + p.v_off + 4 * li]);
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
         const int j = jb + 8 * i;
@@ -336,13 +334,15 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
       float4 kq[KB], vq[KB], xq[KB], ox[KB];
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
-        const int j = jb + 8 * i;
-        if (j < sl) {
-          kq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.k_off + 4 * li]);
-          vq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + j) * p.ld_kv + p.v_off + 4 * li]);
-          xq[i] = *reinterpret_cast<const float4 *>(&p.x[(row0 + j) * D + 4 * li]);
-          if (p.accumulate_dx) ox[i] = *reinterpret_cast<const float4 *>(&p.d_x[(row0 + j) * D + 4 * li]);
-        }
+        const int jc = min(jb + 8 * i, L - 1);
+        kq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.k_off + 4 * li]);
+        vq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.v_off + 4 * li]);
+        xq[i] = *reinterpret_cast<const float4 *>(&p.x[(row0 + jc) * D + 4 * li]);
+      }
+      if (p.accumulate_dx) {              // block-uniform
+#pragma unroll
+        for (int i = 0; i < KB; ++i)
+          ox[i] = *reinterpret_cast<const float4 *>(&p.d_x[(row0 + min(jb + 8 * i, L - 1)) * D + 4 * li]);
       }
 #pragma unroll
       for (int i = 0; i < KB; ++i) {

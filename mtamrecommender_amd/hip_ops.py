@@ -10,7 +10,8 @@ import torch
 
 from . import _lib
 
-EPI_STORE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_ADD, EPI_ACCUM, EPI_ACCUM_MASK, EPI_ATOMIC, EPI_ACCUM2_MASK = range(8)
+EPI_STORE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_ADD, EPI_ACCUM, EPI_ACCUM_MASK, EPI_ATOMIC, EPI_ACCUM2_MASK, \
+    EPI_STORE_SQ = range(9)
 D = 128
 
 
@@ -59,6 +60,10 @@ def gemm(a, b, c, trans_a=False, trans_b=False, epilogue=EPI_STORE, bias=None, a
     _lib.check(rc, "mtam_gemm_f32")
 
 
+def gemm_sq_partials(M, N):
+    return _lib.load().mtam_gemm_sq_partials(M, N)
+
+
 def gemm_batched(a, b, c, M, N, K, lda, sa, ldb, sb, ldc, sc, batch, trans_a=False, trans_b=False,
                  epilogue=EPI_STORE):
     """batch = (batch0, batch1); sa/sb/sc = (stride over batch0, stride over batch1) in elements.
@@ -83,13 +88,17 @@ def emb_gather_partials(B, L):
 
 
 def emb_gather_fwd(item_table, cat_table, pos_table, user_table, item_ids, cat_ids, pos_ids, user_ids,
-                   B, L, with_user, ic_out, pos_out, user_out, l2_partial):
+                   B, L, with_user, ic_out, pos_out, user_out, l2_partial, clear=()):
+    """clear: up to two flat float tensors zeroed by the same launch (the step's gradient accumulators)."""
     lib = _lib.load()
-    rc = lib.mtam_emb_gather_fwd(_p(item_table), item_table.shape[0], _p(cat_table), cat_table.shape[0],
-                                 _p(pos_table), pos_table.shape[0], _p(user_table), user_table.shape[0],
-                                 _pi(item_ids), _pi(cat_ids), _pi(pos_ids), _pi(user_ids), B, L,
-                                 int(with_user), _p(ic_out), _p(pos_out), _p(user_out), _p(l2_partial),
-                                 _stream())
+    ca = clear[0] if len(clear) > 0 else None
+    cb = clear[1] if len(clear) > 1 else None
+    rc = lib.mtam_emb_gather_fwd_clear(_p(item_table), item_table.shape[0], _p(cat_table), cat_table.shape[0],
+                                       _p(pos_table), pos_table.shape[0], _p(user_table), user_table.shape[0],
+                                       _pi(item_ids), _pi(cat_ids), _pi(pos_ids), _pi(user_ids), B, L,
+                                       int(with_user), _p(ic_out), _p(pos_out), _p(user_out), _p(l2_partial),
+                                       _p(ca), ca.numel() if ca is not None else 0,
+                                       _p(cb), cb.numel() if cb is not None else 0, _stream())
     _lib.check(rc, "mtam_emb_gather_fwd")
 
 

@@ -675,3 +675,22 @@ def test_opt_update_matches_the_tf_formulas(ops, kind):
     if kind != "sgd":
         assert rel_err(s1.cpu().numpy(), flat(state.s1)) < 2e-6
         assert rel_err(s2.cpu().numpy(), flat(state.s2)) < 2e-5
+
+
+def test_gemm_store_sq_epilogue(ops):
+    """STORE_SQ: C as STORE, plus per-wave partial sums of C^2 (ragged tile edges excluded)."""
+    rng = np.random.default_rng(21)
+    M, N, K = 3709, 128, 128                      # the dense item gradient: logits^T [V, B] x pred [B, D]
+    a = rng.standard_normal((K, M)).astype(np.float32)
+    b = rng.standard_normal((K, N)).astype(np.float32)
+    c = torch.zeros((M, N), device="cuda")
+    n = ops.gemm_sq_partials(M, N)
+    assert n == 4 * 58 * 2
+    part = torch.full((n,), 7.0, device="cuda")
+    ops.gemm(dev(a), dev(b), c, trans_a=True, epilogue=ops.EPI_STORE_SQ, aux_out=part)
+    ref = a.astype(np.float64).T @ b.astype(np.float64)
+    assert rel_err(c.cpu().numpy(), ref) < 1e-5
+    assert abs(float(part.double().sum()) - float((ref ** 2).sum())) / float((ref ** 2).sum()) < 1e-5
+    c2 = torch.zeros((M, N), device="cuda")
+    ops.gemm(dev(a), dev(b), c2, trans_a=True)
+    assert torch.equal(c, c2)
