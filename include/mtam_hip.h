@@ -183,6 +183,7 @@ int mtam_emb_scatter_add_bwd(const float *d_item_cat, const float *d_pos,
  *   wh_g    [D, 2D], wh_c [D, D]      recurrent halves of gates/candidate kernels
  *   tvec    [8, D]: _time_kernel_w1, _time_kernel_b1, _time_history_w1, _time_w1,
  *                   _time_b1, _time_kernel_w2, _time_w12, _time_b12
+ *           tvec == NULL selects the plain tf GRUCell (Model/Modules/gru.py:13-39,60-67): no time gate
  *   hs      [B*L, D] outputs (zero for t >= seq_len-1), short_out [B, D]
  *   save    [B*L, 5D] or NULL: per step r | u | c | T | h_prev   (for backward)
  */
@@ -193,12 +194,14 @@ int mtam_tagru_fwd(const float *xproj, const float *x, const float *timelast,
 
 /* Backward through time of the above.
  *   d_short [B, D]  gradient of short_out
+ *   d_hs    [B*L, D] or NULL: gradient of every output row hs[t] (the family members whose decoder
+ *           attends over the GRU outputs, Model/MTAMRec_model.py:180,214)
  *   d_xproj [B*L, 3D] out: d(gate pre-act) | d(candidate pre-act), zero for dead steps
  *   rh      [B*L, D] out: r * h_prev (A operand of the candidate-kernel gradient)
  *   d_xt    [B*L, D] out: the time-gate path of d loss / d x (dtw * _time_kernel_w1), zero for dead steps
  *   d_tvec_partial [B, 8, D] out: per-sample gradients of tvec (caller column-sums)
  */
-int mtam_tagru_bwd(const float *d_short, const float *x, const float *timelast,
+int mtam_tagru_bwd(const float *d_short, const float *d_hs, const float *x, const float *timelast,
                    const int32_t *seq_len, const float *wh_g, const float *wh_c,
                    const float *tvec, const float *save, int B, int L,
                    float *d_xproj, float *rh, float *d_xt, float *d_tvec_partial,

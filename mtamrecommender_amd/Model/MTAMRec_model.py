@@ -1,5 +1,6 @@
 """MTAM: time-aware GRU -> time-aware attention decoder -> full-catalog softmax.
-Mirror of Model/MTAMRec_model.py:12-38 (MTAMRec_model) and :61-92 (MTAM)."""
+Mirror of Model/MTAMRec_model.py:12-38 (MTAMRec_model), :61-92 (MTAM) and the ablation members that
+run on the same kernels (:40-59, :93-127, :167-238)."""
 import numpy as np
 
 from .base_model import base_model
@@ -28,13 +29,14 @@ class MTAMRec_model(base_model):
 
 class MTAM(MTAMRec_model):
     """Multi-hop Time-aware Attentive Memory network."""
+    VARIANT = "MTAM"
 
     def build_model(self, seed=1234):
         D, L, NB = self.num_units, self.max_len, self.num_blocks
         if self.embedding.position_count != L:
             raise ValueError("embedding max_length_seq %d != length_of_user_history %d"
                              % (self.embedding.position_count, L))
-        specs = mtam_dense_specs(D, L, NB)
+        specs = mtam_dense_specs(D, L, NB, self.VARIANT)
         values = init_variables(specs, seed=seed + 1)
         live = {s.name: values[s.name] for s in specs if s.trainable_grad}
         self.dead_variables = {s.name: values[s.name] for s in specs if not s.trainable_grad}
@@ -42,7 +44,7 @@ class MTAM(MTAMRec_model):
         self.path = TimeAwarePath(self.embedding.tables(), live, L, self.num_heads, NB,
                                   self.regulation_rate, self.FLAGS.max_gradient_norm,
                                   tf_compat_global_norm=self.FLAGS.tf_compat_global_norm, device=device,
-                                  optimizer=self.opt)
+                                  optimizer=self.opt, variant=self.VARIANT)
         self.summery()
 
     # weight injection for parity tests / checkpoint interchange (TF names)
@@ -67,3 +69,24 @@ class MTAM(MTAMRec_model):
             out["embedding_layer/" + k] = v
         out.update(self.dead_variables)
         return out
+
+
+class MTAM_only_time_aware_RNN(MTAM):
+    """Model/MTAMRec_model.py:40-59: time-aware GRU -> layer_norm -> scoring (no decoder)."""
+    VARIANT = "MTAM_only_time_aware_RNN"
+
+
+class MTAM_no_time_aware_rnn(MTAM):
+    """Model/MTAMRec_model.py:93-127: the plain tf GRUCell encodes the short-term intent."""
+    VARIANT = "MTAM_no_time_aware_rnn"
+
+
+class MTAM_via_T_GRU(MTAM):
+    """Model/MTAMRec_model.py:167-204: the decoder attends over the time-aware GRU's outputs; the
+    short-term intent is layer-normed before it enters the decoder."""
+    VARIANT = "MTAM_via_T_GRU"
+
+
+class MTAM_via_rnn(MTAM):
+    """Model/MTAMRec_model.py:206-238: as MTAM_via_T_GRU with the plain GRUCell."""
+    VARIANT = "MTAM_via_rnn"

@@ -23,7 +23,7 @@ import collections
 
 import numpy as np
 
-from .variables import GRU_DEAD, GRU_SCOPE, GRU_USED, TIME_GATE
+from .variables import GRU_DEAD, GRU_USED, MTAM_VARIANTS, SHORT_LN, TIME_GATE, gru_scope, head_ln_scope
 
 Segment = collections.namedtuple("Segment", "name offset shape size")
 
@@ -36,14 +36,21 @@ class DenseLayout(object):
 
     def __init__(self, model, D, L, num_blocks):
         self.model, self.D, self.L, self.NB = model, D, L, num_blocks
+        self.mtam = model in MTAM_VARIANTS
+        self.cfg = MTAM_VARIANTS.get(model)
         segs = [("dense4emb/w", (2 * D, D))]
-        if model == "MTAM":
+        if self.mtam:
             segs += [("gru/wx", (D, 3 * D)), ("gru/bx", (3 * D,)), ("gru/wh_g", (D, 2 * D)),
-                     ("gru/wh_c", (D, D)), ("gru/tvec", (8, D)),
-                     ("kv/w", (D, 2 * num_blocks * D)), ("kv/b", (2 * num_blocks * D,))]
-            for i in range(num_blocks):
-                segs += [("blk%d/wqt" % i, (D, 2 * D)), ("blk%d/bq" % i, (D,)),
-                         ("blk%d/tparams" % i, (5, L)), ("blk%d/ln" % i, (2, D))]
+                     ("gru/wh_c", (D, D))]
+            if self.cfg["gru"] == "time":
+                segs.append(("gru/tvec", (8, D)))
+            if self.cfg["short_ln"]:
+                segs.append(("short/ln", (2, D)))
+            if self.cfg["attention"]:
+                segs += [("kv/w", (D, 2 * num_blocks * D)), ("kv/b", (2 * num_blocks * D,))]
+                for i in range(num_blocks):
+                    segs += [("blk%d/wqt" % i, (D, 2 * D)), ("blk%d/bq" % i, (D,)),
+                             ("blk%d/tparams" % i, (5, L)), ("blk%d/ln" % i, (2, D))]
         else:
             for i in range(num_blocks):
                 segs += [("blk%d/wqkv" % i, (D, 3 * D)), ("blk%d/bqkv" % i, (3 * D,)),
@@ -65,9 +72,10 @@ class DenseLayout(object):
 
     # ------------------------------------------------------------ TF <-> native
     def _scopes(self):
-        if self.model == "MTAM":
-            return ["NextItemDecoder/decoder/num_blocks_%d/" % i for i in range(self.NB)], "vanilla_attention", \
-                "NextItemDecoder/LayerNorm/"
+        if self.mtam:
+            blocks = ["NextItemDecoder/decoder/num_blocks_%d/" % i for i in range(self.NB)] \
+                if self.cfg["attention"] else []
+            return blocks, "vanilla_attention", head_ln_scope(self.model)
         return ["UserHistoryEncoder/encoder/num_blocks_%d/" % i for i in range(self.NB)], "self_attention", \
             "UserHistoryEncoder/LayerNorm/"
 
@@ -82,17 +90,22 @@ class DenseLayout(object):
 
         put("dense4emb/w", tf_vars["position_embedding/dense4emb/kernel"])
         scopes, inner, head = self._scopes()
-        if self.model == "MTAM":
+        if self.mtam:
+            GRU_SCOPE = gru_scope(self.model)
             Wg, Wc = tf_vars[GRU_SCOPE + "gates/kernel"], tf_vars[GRU_SCOPE + "candidate/kernel"]
             put("gru/wx", np.concatenate([Wg[:D], Wc[:D]], axis=1))
             put("gru/bx", np.concatenate([tf_vars[GRU_SCOPE + "gates/bias"], tf_vars[GRU_SCOPE + "candidate/bias"]]))
             put("gru/wh_g", Wg[D:])
             put("gru/wh_c", Wc[D:])
-            put("gru/tvec", np.stack([tf_vars[GRU_SCOPE + n] for n in GRU_USED]))
-            put("kv/w", np.concatenate([np.concatenate([tf_vars[s + "dense_1/kernel"], tf_vars[s + "dense_2/kernel"]], axis=1)
-                                        for s in scopes], axis=1))
-            put("kv/b", np.concatenate([np.concatenate([tf_vars[s + "dense_1/bias"], tf_vars[s + "dense_2/bias"]])
-                                        for s in scopes]))
+            if self.cfg["gru"] == "time":
+                put("gru/tvec", np.stack([tf_vars[GRU_SCOPE + n] for n in GRU_USED]))
+            if self.cfg["short_ln"]:
+                put("short/ln", np.stack([tf_vars[SHORT_LN + "beta"], tf_vars[SHORT_LN + "gamma"]]))
+            if scopes:
+                put("kv/w", np.concatenate([np.concatenate([tf_vars[s + "dense_1/kernel"], tf_vars[s + "dense_2/kernel"]],
+                                                           axis=1) for s in scopes], axis=1))
+                put("kv/b", np.concatenate([np.concatenate([tf_vars[s + "dense_1/bias"], tf_vars[s + "dense_2/bias"]])
+                                            for s in scopes]))
             for i, s in enumerate(scopes):
                 a = s + inner + "/"
                 put("blk%d/wqt" % i, np.concatenate([tf_vars[s + "dense/kernel"], tf_vars[a + "_time_input_w"]], axis=1))
@@ -119,16 +132,21 @@ class DenseLayout(object):
         out = collections.OrderedDict()
         out["position_embedding/dense4emb/kernel"] = get("dense4emb/w")
         scopes, inner, head = self._scopes()
-        if self.model == "MTAM":
+        if self.mtam:
+            GRU_SCOPE = gru_scope(self.model)
             wx, bx = get("gru/wx"), get("gru/bx")
             out[GRU_SCOPE + "gates/kernel"] = np.concatenate([wx[:, :2 * D], get("gru/wh_g")], axis=0)
             out[GRU_SCOPE + "gates/bias"] = bx[:2 * D]
             out[GRU_SCOPE + "candidate/kernel"] = np.concatenate([wx[:, 2 * D:], get("gru/wh_c")], axis=0)
             out[GRU_SCOPE + "candidate/bias"] = bx[2 * D:]
-            tv = get("gru/tvec")
-            for j, n in enumerate(GRU_USED):
-                out[GRU_SCOPE + n] = tv[j]
-            kvw, kvb = get("kv/w"), get("kv/b")
+            if self.cfg["gru"] == "time":
+                tv = get("gru/tvec")
+                for j, n in enumerate(GRU_USED):
+                    out[GRU_SCOPE + n] = tv[j]
+            if self.cfg["short_ln"]:
+                sl_ = get("short/ln")
+                out[SHORT_LN + "beta"], out[SHORT_LN + "gamma"] = sl_[0], sl_[1]
+            kvw, kvb = (get("kv/w"), get("kv/b")) if scopes else (None, None)
             for i, s in enumerate(scopes):
                 a = s + inner + "/"
                 wqt = get("blk%d/wqt" % i)
@@ -164,6 +182,6 @@ class DenseLayout(object):
         """Variables the reference creates but never updates (gradient None)."""
         scopes, inner, _ = self._scopes()
         names = [s + inner + "/time_output_w3" for s in scopes]
-        if self.model == "MTAM":
-            names += [GRU_SCOPE + n for n in GRU_DEAD]
+        if self.mtam and self.cfg["gru"] == "time":
+            names += [gru_scope(self.model) + n for n in GRU_DEAD]
         return names

@@ -55,14 +55,6 @@ def arena_layout(B, L):
     return offsets, o
 
 
-class _Inline(object):
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
-
-
 class _Batch(object):
     """Per-batch-size device buffers (activations, gradients, saved state)."""
 
@@ -85,7 +77,9 @@ class _Batch(object):
         self.xproj, self.hs, self.short = f(R, 3 * D), f(R, D), f(B, D)
         self.gru_save = f(R, 5 * D)
         self.kv = f(R, 2 * NB * D)
-        self.dec = [self.short] + [f(B, D) for _ in range(NB)]
+        # decoder input: the short-term intent, layer-normed first in the via_* members
+        self.short_n, self.short_ln_save = f(B, D), f(B, D + 1)
+        self.dec = [self.short_n if path.cfg["short_ln"] else self.short] + [f(B, D) for _ in range(NB)]
         self.attn_save = [f(B, ops.ta_attn_decode_save_floats(L, H)) for _ in range(NB)]
         self.pred, self.ln_save = f(B, D), f(B, D + 1)
         self.logits = f(B, V)
@@ -103,7 +97,14 @@ class _Batch(object):
         self.d_xproj, self.rh = f(R, 3 * D), f(R, D)
         self.d_tvec_partial = f(B, 8 * D)
         self.d_ic = f(R, 2 * D)
-        self.d_pred = f(B, D)
+        # [d_pred | d_x]: cleared together by the step's first kernel when the decoder's key gradient goes
+        # to the GRU outputs (d_hs) and d_x only receives the GRU's input-path gradient
+        self.d_clear = f(B * D + R * D)
+        self.d_pred = self.d_clear[:B * D].view(B, D)
+        if path.cfg["keys"] == "gru":
+            self.d_x = self.d_clear[B * D:].view(R, D)
+            self.d_hs = f(R, D)
+        self.d_short = f(B, D)
         self.n_slot = ops.emb_scatter_partials(B, L)
         self.norm_partial = torch.zeros(path.nb_all + self.n_slot, dtype=torch.float32, device=dev)
         self.topk_idx = torch.zeros((B, 50), dtype=torch.int32, device=dev)
@@ -121,7 +122,7 @@ class TimeAwarePath(object):
     BATCH_CLASS = None       # set below
 
     def __init__(self, tables, dense_tf, L, num_heads, num_blocks, regulation_rate, max_gradient_norm,
-                 tf_compat_global_norm=True, device="cuda:0", optimizer="adam"):
+                 tf_compat_global_norm=True, device="cuda:0", optimizer="adam", variant=None):
         self.device = dev = torch.device(device)
         self.L, self.H, self.NB = L, num_heads, num_blocks
         self.reg, self.clip = float(regulation_rate), float(max_gradient_norm)
@@ -129,6 +130,10 @@ class TimeAwarePath(object):
         if optimizer not in ("adam", "sgd", "adadelta", "rmsprop"):
             raise ValueError("unknown optimizer %r" % (optimizer,))
         self.optimizer = optimizer
+        from .variables import MTAM_VARIANTS
+        if variant is not None:
+            self.MODEL = variant
+        self.cfg = MTAM_VARIANTS.get(self.MODEL, dict(gru=None, keys="x", short_ln=False, attention=True))
         self.layout = DenseLayout(self.MODEL, D, L, num_blocks)
         for k, v in tables.items():
             if v.shape[1] != D:
@@ -171,13 +176,9 @@ class TimeAwarePath(object):
         self.adam_state = torch.tensor([0.0, 0.9, 0.999, 1e-8, 0.9, 0.999, 0.0, 0.0], dtype=torch.float32,
                                        device=dev)
         self._batches = {}
-        # side streams: independent branches of the step (K/V projection next to the GRU, the dense
-        # item gradient and the weight-gradient GEMMs next to the serial backward chain) run
-        # concurrently; under hipGraph capture the waits become graph edges.
-        # Measured on MI355X at B=128: 388 us/step with the branches on side streams vs 366 us in one
-        # stream -- the cross-queue graph edges cost more than the overlap wins -- so it is off by default.
-        self.side = [torch.cuda.Stream(device=dev) for _ in range(4)]
-        self.overlap = False
+        # (Independent branches of the step were tried on side streams -- K/V projection next to the GRU,
+        # weight-gradient GEMMs next to the serial chain: 388 us/step vs 366 us in one stream at B=128; the
+        # cross-queue graph edges cost more than the overlap won, so the step is single-stream.)
         self.allreduce_fn = None        # set by data_parallel.attach()
         self.world_size = 1             # the loss is a mean over world_size * B samples
 
@@ -210,48 +211,42 @@ class TimeAwarePath(object):
         self.fill_host(bt, feed, lr)
         return bt.host_arena.to(self.device, non_blocking=False)
 
-    # ------------------------------------------------------------ stream plumbing
-    def _fork(self, i):
-        """Run the following `with` block on side stream i, ordered after everything enqueued so far
-        on the current stream.  With overlap disabled the block simply runs in line."""
-        if not self.overlap:
-            return _Inline()
-        side = self.side[i]
-        side.wait_stream(torch.cuda.current_stream())
-        return torch.cuda.stream(side)
-
-    def _join(self, *idx):
-        if self.overlap:
-            cur = torch.cuda.current_stream()
-            for i in idx:
-                cur.wait_stream(self.side[i])
-
     # ----------------------------------------------------------------- forward
     def forward(self, bt, training=True):
+        """Model/MTAMRec_model.py:40-238 (the member is chosen by ``self.cfg``)."""
         B, R, L, NB, H = bt.B, bt.R, self.L, self.NB, self.H
-        fd, T = bt.feed, self.tables
+        fd, T, cfg = bt.feed, self.tables, self.cfg
         ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
                            fd["category_list"], fd["position_list"], fd["user_id"], B, L, 1,
                            bt.ic, bt.pos, bt.user, bt.l2_partial,
                            # a training step's first kernel also clears its gradient accumulators
-                           clear=(self.zero_prefix, bt.d_pred.view(-1)) if training else ())
+                           clear=(self.zero_prefix, bt.d_clear if cfg["keys"] == "gru" else bt.d_pred.view(-1))
+                           if training else ())
         ops.gemm(bt.ic, self.seg("dense4emb/w"), bt.x, epilogue=ops.EPI_RELU_ADD, aux_in=bt.pos, aux_out=bt.zr)
-        with self._fork(0):          # keys/values of every block: independent of the GRU
+        keys = bt.hs if cfg["keys"] == "gru" else bt.x        # user_history: what the decoder attends over
+        if cfg["attention"] and cfg["keys"] == "x":           # keys/values of every block (before the GRU)
             ops.gemm(bt.x, self.seg("kv/w"), bt.kv, epilogue=ops.EPI_BIAS_RELU, bias=self.seg("kv/b"))
         ops.gemm(bt.x, self.seg("gru/wx"), bt.xproj, epilogue=ops.EPI_BIAS, bias=self.seg("gru/bx"))
+        tvec = self.seg("gru/tvec") if cfg["gru"] == "time" else None
         ops.tagru_fwd(bt.xproj, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
-                      self.seg("gru/wh_c"), self.seg("gru/tvec"), B, L, bt.hs, bt.short,
-                      bt.gru_save if training else None)
-        self._join(0)
-        for i in range(NB):
-            ln = self.seg("blk%d/ln" % i)
-            ops.ta_attn_decode_fwd(bt.dec[i], bt.x, bt.kv, 2 * NB * D, 2 * i * D, (2 * i + 1) * D,
-                                   fd["target_item_time"], fd["time_list"], fd["seq_length"],
-                                   self.seg("blk%d/wqt" % i), self.seg("blk%d/bq" % i),
-                                   self.seg("blk%d/tparams" % i), ln[0], ln[1], B, L, H, bt.dec[i + 1],
-                                   bt.attn_save[i] if training else None)
+                      self.seg("gru/wh_c"), tvec, B, L, bt.hs, bt.short, bt.gru_save if training else None)
+        if cfg["short_ln"]:
+            sl = self.seg("short/ln")
+            ops.layer_norm_fwd(bt.short, sl[0], sl[1], 1e-12, B, bt.short_n, bt.short_ln_save if training else None)
+        if cfg["attention"] and cfg["keys"] == "gru":
+            ops.gemm(bt.hs, self.seg("kv/w"), bt.kv, epilogue=ops.EPI_BIAS_RELU, bias=self.seg("kv/b"))
+        last = bt.short
+        if cfg["attention"]:
+            for i in range(NB):
+                ln = self.seg("blk%d/ln" % i)
+                ops.ta_attn_decode_fwd(bt.dec[i], keys, bt.kv, 2 * NB * D, 2 * i * D, (2 * i + 1) * D,
+                                       fd["target_item_time"], fd["time_list"], fd["seq_length"],
+                                       self.seg("blk%d/wqt" % i), self.seg("blk%d/bq" % i),
+                                       self.seg("blk%d/tparams" % i), ln[0], ln[1], B, L, H, bt.dec[i + 1],
+                                       bt.attn_save[i] if training else None)
+            last = bt.dec[NB]
         hl = self.seg("head/ln")
-        ops.layer_norm_fwd(bt.dec[NB], hl[0], hl[1], 1e-12, B, bt.pred, bt.ln_save if training else None)
+        ops.layer_norm_fwd(last, hl[0], hl[1], 1e-12, B, bt.pred, bt.ln_save if training else None)
         ops.gemm(bt.pred, T["item"], bt.logits, trans_b=True)
 
     def loss_and_logit_grad(self, bt):
@@ -265,86 +260,82 @@ class TimeAwarePath(object):
     # ---------------------------------------------------------------- backward
     def backward(self, bt):
         B, R, L, NB, H = bt.B, bt.R, self.L, self.NB, self.H
-        fd, T, G = bt.feed, self.tables, self.grads
+        fd, T, G, cfg = bt.feed, self.tables, self.grads, self.cfg
         gseg = lambda name: self.layout.view(G, name)
         part = bt.norm_partial
         sr = max(1, min(16, R // 256))
         prob = lambda A, lda, Bm, ldb, name, M, N, K, s: dict(A=A, lda=lda, B=Bm, ldb=ldb, C=gseg(name),
                                                               ldc=N, M=M, N=N, K=K, split_k=s)
-        # Side 1: dense item gradient dE = G^T pred (every row) and its share of the TF global norm.
-        # Only the scatter at the very end needs it.
-        with self._fork(1):
-            if self.tf_compat:
-                ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True, epilogue=ops.EPI_STORE_SQ,
-                         aux_out=part[self.nb_dense:])
-            else:
-                ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
-        # Main chain: d_pred = G E -> head LN -> decoder blocks (last to first)
+        # dense item gradient dE = G^T pred (every row) and its share of the TF global norm
+        if self.tf_compat:
+            ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True, epilogue=ops.EPI_STORE_SQ,
+                     aux_out=part[self.nb_dense:])
+        else:
+            ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
+        # d_pred = G E -> head LN -> decoder blocks (last to first)
         split_v = max(1, min(64, (self.item_rows + 127) // 128))
         ops.gemm(bt.logits, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v)
-        ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_dec[NB], gseg("head/ln"))
-        for i in reversed(range(NB)):
-            ln = self.seg("blk%d/ln" % i)
-            ops.ta_attn_decode_bwd(bt.d_dec[i + 1], bt.dec[i], bt.x, bt.kv, 2 * NB * D, 2 * i * D,
-                                   (2 * i + 1) * D, fd["target_item_time"], fd["time_list"],
-                                   fd["seq_length"], self.seg("blk%d/wqt" % i), self.seg("blk%d/tparams" % i),
-                                   ln[1], bt.attn_save[i], B, L, H, 0 if i == NB - 1 else 1,
-                                   bt.d_dec[i], bt.d_kv, bt.d_x, bt.d_qt[i], bt.d_tp_partial[i],
-                                   bt.d_ln_partial[i])
-        kv_problems = [prob(bt.x, D, bt.d_kv, 2 * NB * D, "kv/w", D, 2 * NB * D, R, sr)] + \
-            [prob(bt.dec[i], D, bt.d_qt[i], 2 * D, "blk%d/wqt" % i, D, 2 * D, B, 1) for i in range(NB)]
-        kv_jobs = [(bt.d_kv, R, 2 * NB * D, 2 * NB * D, gseg("kv/b"))]
-        for i in range(NB):
-            kv_jobs += [(bt.d_qt[i], B, D, 2 * D, gseg("blk%d/bq" % i)),
-                        (bt.d_tp_partial[i], B, 5 * L, 5 * L, gseg("blk%d/tparams" % i).view(-1)),
-                        (bt.d_ln_partial[i], B, 2 * D, 2 * D, gseg("blk%d/ln" % i).view(-1))]
-        gru_problems = [
-            prob(bt.x, D, bt.d_xproj, 3 * D, "gru/wx", D, 3 * D, R, sr),
-            prob(bt.gru_save.view(-1)[4 * D:], 5 * D, bt.d_xproj, 3 * D, "gru/wh_g", D, 2 * D, R, sr),
-            prob(bt.rh, D, bt.d_xproj.view(-1)[2 * D:], 3 * D, "gru/wh_c", D, D, R, sr)]
-        gru_jobs = [(bt.d_xproj, R, 3 * D, 3 * D, gseg("gru/bx")),
-                    (bt.d_tvec_partial, B, 8 * D, 8 * D, gseg("gru/tvec").view(-1))]
-        w4_problem = [prob(bt.ic, 2 * D, bt.d_z, D, "dense4emb/w", 2 * D, D, R, sr)]
-
-        def grouped(problems, jobs):
-            for chunk in _chunks(problems, MAX_GROUP):
-                ops.gemm_tn_atomic_grouped(chunk)
-            for chunk in _chunks(jobs, MAX_GROUP):
-                ops.colsum_atomic_multi(chunk)
-
-        # Side 2: what only needs the attention gradients -- d_x += d_kv . Wkv^T, then dWkv, dWqt and
-        # the attention bias-like gradients -- may run next to the GRU's backward-through-time.
-        with self._fork(2):
-            ops.gemm(bt.d_kv, self.seg("kv/w"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM)
-            if self.overlap:
-                grouped(kv_problems, kv_jobs)
-        # Main: GRU back through time (its time-gate path goes to d_xt, not into d_x, so that it does
-        # not race with side 2's accumulation into d_x)
-        ops.tagru_bwd(bt.d_dec[0], bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
-                      self.seg("gru/wh_c"), self.seg("gru/tvec"), bt.gru_save, B, L, bt.d_xproj, bt.rh,
-                      bt.d_xt, bt.d_tvec_partial)
-        if self.overlap:
-            with self._fork(3):          # GRU weight and bias-like gradients
-                grouped(gru_problems, gru_jobs)
-        # Main: d_x += d_xproj . Wx^T + d_xt, d_z = d_x where relu(z) > 0; then d[item|cat]
-        self._join(2)
+        keys = bt.hs if cfg["keys"] == "gru" else bt.x
+        d_keys = bt.d_hs if cfg["keys"] == "gru" else bt.d_x      # gradient of user_history
+        problems, jobs = [], []
+        if cfg["attention"]:
+            ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_dec[NB], gseg("head/ln"))
+            for i in reversed(range(NB)):
+                ln = self.seg("blk%d/ln" % i)
+                ops.ta_attn_decode_bwd(bt.d_dec[i + 1], bt.dec[i], keys, bt.kv, 2 * NB * D, 2 * i * D,
+                                       (2 * i + 1) * D, fd["target_item_time"], fd["time_list"],
+                                       fd["seq_length"], self.seg("blk%d/wqt" % i), self.seg("blk%d/tparams" % i),
+                                       ln[1], bt.attn_save[i], B, L, H, 0 if i == NB - 1 else 1,
+                                       bt.d_dec[i], bt.d_kv, d_keys, bt.d_qt[i], bt.d_tp_partial[i],
+                                       bt.d_ln_partial[i])
+            problems += [prob(keys, D, bt.d_kv, 2 * NB * D, "kv/w", D, 2 * NB * D, R, sr)] + \
+                [prob(bt.dec[i], D, bt.d_qt[i], 2 * D, "blk%d/wqt" % i, D, 2 * D, B, 1) for i in range(NB)]
+            jobs += [(bt.d_kv, R, 2 * NB * D, 2 * NB * D, gseg("kv/b"))]
+            for i in range(NB):
+                jobs += [(bt.d_qt[i], B, D, 2 * D, gseg("blk%d/bq" % i)),
+                         (bt.d_tp_partial[i], B, 5 * L, 5 * L, gseg("blk%d/tparams" % i).view(-1)),
+                         (bt.d_ln_partial[i], B, 2 * D, 2 * D, gseg("blk%d/ln" % i).view(-1))]
+            # d(user_history) += d_kv . Wkv^T
+            ops.gemm(bt.d_kv, self.seg("kv/w"), d_keys, trans_b=True, epilogue=ops.EPI_ACCUM)
+            d_short = bt.d_dec[0]
+        else:
+            ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_short, gseg("head/ln"))
+            d_short = bt.d_short
+        if cfg["short_ln"]:
+            ops.layer_norm_bwd(d_short, self.seg("short/ln")[1], bt.short_ln_save, B, bt.d_short, gseg("short/ln"))
+            d_short = bt.d_short
+        # GRU back through time (its time-gate path goes to d_xt); with the GRU outputs as keys their
+        # gradient enters every step
+        tvec = self.seg("gru/tvec") if cfg["gru"] == "time" else None
+        ops.tagru_bwd(d_short, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
+                      self.seg("gru/wh_c"), tvec, bt.gru_save, B, L, bt.d_xproj, bt.rh, bt.d_xt,
+                      bt.d_tvec_partial, d_hs=bt.d_hs if cfg["keys"] == "gru" else None)
+        problems = [prob(bt.x, D, bt.d_xproj, 3 * D, "gru/wx", D, 3 * D, R, sr),
+                    prob(bt.gru_save.view(-1)[4 * D:], 5 * D, bt.d_xproj, 3 * D, "gru/wh_g", D, 2 * D, R, sr),
+                    prob(bt.rh, D, bt.d_xproj.view(-1)[2 * D:], 3 * D, "gru/wh_c", D, D, R, sr)] + problems
+        jobs = [(bt.d_xproj, R, 3 * D, 3 * D, gseg("gru/bx"))] + jobs
+        if cfg["gru"] == "time":
+            jobs.append((bt.d_tvec_partial, B, 8 * D, 8 * D, gseg("gru/tvec").view(-1)))
+        # d_x (+)= d_xproj . Wx^T + d_xt, d_z = d_x where relu(z) > 0; then d[item|cat].  d_x already holds the
+        # decoder's key gradient when the keys are x; otherwise it was cleared by the step's first kernel
+        # (members without a decoder leave it untouched: cleared here)
+        if not cfg["attention"]:
+            bt.d_x.zero_()
         ops.gemm(bt.d_xproj, self.seg("gru/wx"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM2_MASK,
                  bias=bt.d_xt, aux_in=bt.zr, aux_out=bt.d_z)
-        if self.overlap:
-            with self._fork(2):
-                grouped(w4_problem, [])
         ops.gemm(bt.d_z, self.seg("dense4emb/w"), bt.d_ic, trans_b=True)
-        if not self.overlap:
-            # one stream: every weight gradient in ONE grouped launch, every bias-like one in ONE launch
-            grouped(gru_problems + kv_problems + w4_problem, gru_jobs + kv_jobs)
+        problems.append(prob(bt.ic, 2 * D, bt.d_z, D, "dense4emb/w", 2 * D, D, R, sr))
+        # every weight gradient in ONE grouped launch, every bias-like one in ONE launch
+        for chunk in _chunks(problems, MAX_GROUP):
+            ops.gemm_tn_atomic_grouped(chunk)
+        for chunk in _chunks(jobs, MAX_GROUP):
+            ops.colsum_atomic_multi(chunk)
         # tables: sparse rows on top of the dense item gradient
-        self._join(1)
         slot_part = part[self.nb_dense + self.nb_item:]
         ops.emb_scatter_add_bwd(bt.d_ic, bt.d_x, bt.ic, bt.pos, bt.user, fd["item_list"], fd["category_list"],
                                 fd["position_list"], fd["user_id"], fd["seq_length"], B, L, self.reg, 1,
                                 self.g_tab["item"], self.g_tab["category"], self.g_tab["position"],
                                 self.g_tab["user"], slot_part)
-        self._join(2, 3)
 
     # ------------------------------------------------------------------ update
     def clip_and_apply(self, bt):

@@ -21,6 +21,31 @@ import math
 import numpy as np
 
 GRU_SCOPE = "ShortTermIntentEncoder/rnn/multi_rnn_cell/cell_0/time_aware_gru_cell_decay_new/"
+PLAIN_GRU_SCOPE = "ShortTermIntentEncoder/rnn/multi_rnn_cell/cell_0/gru_cell/"      # tf GRUCell (gru.py:13-39)
+SHORT_LN = "ShortTermIntentEncoder/LayerNorm/"
+
+# The MTAM family (Model/MTAMRec_model.py:40-306): which recurrent cell encodes the short-term intent,
+# what the decoder attends over, and where layer norms sit.  The three members that need other
+# kernels are not built: MTAM_no_time_aware_att (non-time-aware attention with live dropout,
+# SURVEY.md F8), MTAM_hybird (output_concat head), MTAM_with_T_SeqRec (TimeAwareGRUCell_sigmoid).
+MTAM_VARIANTS = {
+    # name: (gru cell, attention keys, layer_norm on the short-term intent, attention decoder)
+    "MTAM": dict(gru="time", keys="x", short_ln=False, attention=True),                       # :61-92
+    "MTAM_only_time_aware_RNN": dict(gru="time", keys=None, short_ln=False, attention=False),  # :40-59
+    "MTAM_no_time_aware_rnn": dict(gru="plain", keys="x", short_ln=False, attention=True),     # :93-127
+    "MTAM_via_T_GRU": dict(gru="time", keys="gru", short_ln=True, attention=True),             # :167-204
+    "MTAM_via_rnn": dict(gru="plain", keys="gru", short_ln=True, attention=True),              # :206-238
+}
+
+
+def gru_scope(variant):
+    return GRU_SCOPE if MTAM_VARIANTS[variant]["gru"] == "time" else PLAIN_GRU_SCOPE
+
+
+def head_ln_scope(variant):
+    """The layer_norm that produces predict_behavior_emb: inside NextItemDecoder for the members with a
+    decoder, inside ShortTermIntentEncoder for MTAM_only_time_aware_RNN (:58)."""
+    return "NextItemDecoder/LayerNorm/" if MTAM_VARIANTS[variant]["attention"] else SHORT_LN
 GRU_USED = ("_time_kernel_w1", "_time_kernel_b1", "_time_history_w1", "_time_w1",
             "_time_b1", "_time_kernel_w2", "_time_w12", "_time_b12")
 GRU_DEAD = ("_time_history_b1", "_time_kernel_b2", "_time_history_w2", "_time_history_b2",
@@ -64,21 +89,29 @@ def attention_block_specs(scope, inner, D, Tq, Tk):
     return specs
 
 
-def mtam_dense_specs(D, L, num_blocks):
+def mtam_dense_specs(D, L, num_blocks, variant="MTAM"):
+    cfg = MTAM_VARIANTS[variant]
+    G = gru_scope(variant)
     specs = [VarSpec("position_embedding/dense4emb/kernel", (2 * D, D), _glorot((2 * D, D)), True),
-             VarSpec(GRU_SCOPE + "gates/kernel", (2 * D, 2 * D), _glorot((2 * D, 2 * D)), True),
-             VarSpec(GRU_SCOPE + "gates/bias", (2 * D,), ("const", 1.0), True),
-             VarSpec(GRU_SCOPE + "candidate/kernel", (2 * D, D), _glorot((2 * D, D)), True),
-             VarSpec(GRU_SCOPE + "candidate/bias", (D,), ("const", 0.0), True)]
-    for name in GRU_USED:
-        specs.append(VarSpec(GRU_SCOPE + name, (D,), _glorot((D,)), True))
-    for name in GRU_DEAD:
-        specs.append(VarSpec(GRU_SCOPE + name, (D,), _glorot((D,)), False))
-    for i in range(num_blocks):
-        specs += attention_block_specs("NextItemDecoder/decoder/num_blocks_%d/" % i,
-                                       "vanilla_attention", D, 1, L)
-    specs.append(VarSpec("NextItemDecoder/LayerNorm/beta", (D,), ("const", 0.0), True))
-    specs.append(VarSpec("NextItemDecoder/LayerNorm/gamma", (D,), ("const", 1.0), True))
+             VarSpec(G + "gates/kernel", (2 * D, 2 * D), _glorot((2 * D, 2 * D)), True),
+             VarSpec(G + "gates/bias", (2 * D,), ("const", 1.0), True),
+             VarSpec(G + "candidate/kernel", (2 * D, D), _glorot((2 * D, D)), True),
+             VarSpec(G + "candidate/bias", (D,), ("const", 0.0), True)]
+    if cfg["gru"] == "time":
+        for name in GRU_USED:
+            specs.append(VarSpec(G + name, (D,), _glorot((D,)), True))
+        for name in GRU_DEAD:
+            specs.append(VarSpec(G + name, (D,), _glorot((D,)), False))
+    if cfg["short_ln"]:
+        specs.append(VarSpec(SHORT_LN + "beta", (D,), ("const", 0.0), True))
+        specs.append(VarSpec(SHORT_LN + "gamma", (D,), ("const", 1.0), True))
+    if cfg["attention"]:
+        for i in range(num_blocks):
+            specs += attention_block_specs("NextItemDecoder/decoder/num_blocks_%d/" % i,
+                                           "vanilla_attention", D, 1, L)
+    head = head_ln_scope(variant)
+    specs.append(VarSpec(head + "beta", (D,), ("const", 0.0), True))
+    specs.append(VarSpec(head + "gamma", (D,), ("const", 1.0), True))
     return specs
 
 
@@ -94,8 +127,8 @@ def pistrec_dense_specs(D, L, num_blocks):
 
 def model_specs(model, user_count, item_count, category_count, L, D, num_blocks):
     tables = table_specs(user_count, item_count, category_count, L, D)
-    if model == "MTAM":
-        return tables + mtam_dense_specs(D, L, num_blocks)
+    if model in MTAM_VARIANTS:
+        return tables + mtam_dense_specs(D, L, num_blocks, model)
     if model == "PISTRec":
         return tables + pistrec_dense_specs(D, L, num_blocks)
     raise ValueError("unknown model family: %s" % model)

@@ -34,7 +34,7 @@ SIGNATURES = {
     "mtam_emb_scatter_add_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
                                          P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
     "mtam_tagru_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
-    "mtam_tagru_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
+    "mtam_tagru_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
     "mtam_ta_attn_decode_save_floats": (c_int, [c_int, c_int]),
     "mtam_ta_attn_decode_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
                                         c_int, c_int, c_int, P, P, P]),

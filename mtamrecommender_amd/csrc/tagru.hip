@@ -60,12 +60,17 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
   //   threads 128..255  u gate
   //   threads 256..383  time gate T (needs only x_t, dt and the OLD state: off the critical path)
   const int col = tid & (D - 1);
-  const bool is_T = (tid >= 2 * D) && (tid < 3 * D);
+  // tvec == nullptr: the plain tf GRUCell (Model/Modules/gru.py:13-39) -- no time gate, T = 1
+  const bool plain = p.tvec == nullptr;
+  const bool is_T = !plain && (tid >= 2 * D) && (tid < 3 * D);
   float tv[NTV];
 #pragma unroll
   for (int i = 0; i < NTV; ++i) tv[i] = (is_T) ? p.tvec[i * D + col] : 0.f;
 
-  if (tid < D) h_s[tid] = 0.f;
+  if (tid < D) {
+    h_s[tid] = 0.f;
+    T_s[tid] = 1.f;
+  }
 
   // software prefetch of step t's inputs (independent of the recurrence)
   float n_a = 0.f, n_b = 0.f;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
 }
 
 struct BwdArgs {
-  const float *d_short, *x, *timelast;
+  const float *d_short, *d_hs, *x, *timelast;
   const int32_t *seq_len;
   const float *wh_g, *wh_c, *tvec, *save;
   int B, L;
@@ -197,10 +202,11 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
     wgT[4 * q] = f32x2{v0.x, v1.x}; wgT[4 * q + 1] = f32x2{v0.y, v1.y};
     wgT[4 * q + 2] = f32x2{v0.z, v1.z}; wgT[4 * q + 3] = f32x2{v0.w, v1.w};
   }
+  const bool plain = p.tvec == nullptr;       // plain GRUCell: T = 1, no time-gate gradients
   float tv[NTV], gtv[NTV];
 #pragma unroll
   for (int i = 0; i < NTV; ++i) {
-    tv[i] = (tid < D) ? p.tvec[i * D + tid] : 0.f;
+    tv[i] = (tid < D && !plain) ? p.tvec[i * D + tid] : 0.f;
     gtv[i] = 0.f;
   }
 
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
 
   float dh = (tid < D && steps > 0) ? p.d_short[(size_t)b * D + tid] : 0.f;
 
-  float n_r = 0.f, n_u = 0.f, n_c = 0.f, n_T = 0.f, n_hp = 0.f, n_x = 0.f, n_dl = 0.f;
+  float n_r = 0.f, n_u = 0.f, n_c = 0.f, n_T = 0.f, n_hp = 0.f, n_x = 0.f, n_dl = 0.f, n_dhs = 0.f;
   auto prefetch = [&](int t) {
     if (tid < D) {
       const size_t r = row0 + t;
@@ -224,12 +230,14 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
       n_r = sv[0]; n_u = sv[D]; n_c = sv[2 * D]; n_T = sv[3 * D]; n_hp = sv[4 * D];
       n_x = p.x[r * D + tid];
       n_dl = p.timelast[r];
+      if (p.d_hs) n_dhs = p.d_hs[r * D + tid];      // gradient on the step's OUTPUT (decoder keys = GRU outputs)
     }
   };
   if (steps > 0) prefetch(steps - 1);
 
   for (int t = steps - 1; t >= 0; --t) {
     const float r_ = n_r, u = n_u, c = n_c, T = n_T, hp = n_hp, xt = n_x, dl = n_dl;
+    dh += n_dhs;
     if (t > 0) prefetch(t - 1);
     const size_t row = row0 + t;
     float du = 0.f, dhp = 0.f, dcpre = 0.f;
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
       const float twp = xt * tv[KW1] + tv[KB1] + hp * tv[HW1];
       const float tsp = tv[W1] * dl + tv[B1];
       const float tw = fmaxf(twp, 0.f), ts = fmaxf(tsp, 0.f);
-      const float dTp = dT * T * (1.f - T);
+      const float dTp = plain ? 0.f : dT * T * (1.f - T);
       gtv[KW2] += dTp * tw;
       gtv[W12] += dTp * ts;
       gtv[B12] += dTp;
@@ -322,24 +330,24 @@ extern "C" int mtam_tagru_fwd(const float *xproj, const float *x, const float *t
                               const float *tvec, int B, int L, float *hs, float *short_out,
                               float *save, void *stream) {
   MTAM_CHECK_ARG(B > 0 && L > 0, "tagru_fwd: B and L must be positive");
-  MTAM_CHECK_ARG(xproj && x && timelast && seq_len && wh_g && wh_c && tvec && hs && short_out,
-                 "tagru_fwd: null argument");
+  MTAM_CHECK_ARG(xproj && x && timelast && seq_len && wh_g && wh_c && hs && short_out,
+                 "tagru_fwd: null argument");        // tvec may be NULL: plain GRUCell
   FwdArgs a{xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save};
   hipLaunchKernelGGL(tagru_fwd_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("tagru_fwd");
   return MTAM_OK;
 }
 
-extern "C" int mtam_tagru_bwd(const float *d_short, const float *x, const float *timelast,
+extern "C" int mtam_tagru_bwd(const float *d_short, const float *d_hs, const float *x, const float *timelast,
                               const int32_t *seq_len, const float *wh_g, const float *wh_c,
                               const float *tvec, const float *save, int B, int L, float *d_xproj,
                               float *rh, float *d_xt, float *d_tvec_partial, void *stream) {
   MTAM_CHECK_ARG(B > 0 && L > 0, "tagru_bwd: B and L must be positive");
-  MTAM_CHECK_ARG(d_short && x && timelast && seq_len && wh_g && wh_c && tvec && save && d_xproj && rh &&
-                     d_xt && d_tvec_partial,
-                 "tagru_bwd: null argument");
+  MTAM_CHECK_ARG(d_short && x && timelast && seq_len && wh_g && wh_c && save && d_xproj && rh && d_xt &&
+                     d_tvec_partial,
+                 "tagru_bwd: null argument");        // tvec (plain GRUCell) and d_hs may be NULL
   MTAM_CHECK_ARG(mtam_aligned16(wh_g) && mtam_aligned16(wh_c), "tagru_bwd: weights must be 16-byte aligned");
-  BwdArgs a{d_short, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xproj, rh, d_xt, d_tvec_partial};
+  BwdArgs a{d_short, d_hs, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xproj, rh, d_xt, d_tvec_partial};
   hipLaunchKernelGGL(tagru_bwd_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("tagru_bwd");
   return MTAM_OK;

@@ -125,9 +125,9 @@ def tagru_fwd(xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out
 
 
 def tagru_bwd(d_short, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xproj, rh, d_x,
-              d_tvec_partial):
+              d_tvec_partial, d_hs=None):
     lib = _lib.load()
-    rc = lib.mtam_tagru_bwd(_p(d_short), _p(x), _p(timelast), _pi(seq_len), _p(wh_g), _p(wh_c), _p(tvec),
+    rc = lib.mtam_tagru_bwd(_p(d_short), _p(d_hs), _p(x), _p(timelast), _pi(seq_len), _p(wh_g), _p(wh_c), _p(tvec),
                             _p(save), B, L, _p(d_xproj), _p(rh), _p(d_x), _p(d_tvec_partial), _stream())
     _lib.check(rc, "mtam_tagru_bwd")
 

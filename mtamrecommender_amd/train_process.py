@@ -96,10 +96,15 @@ class Train_main_process(object):
     # ------------------------------------------------------------------ pieces
     def build_model(self):
         from .Model.base_model import Session
-        from .Model.MTAMRec_model import MTAM
+        from .Model import MTAMRec_model as family
         self.sess = Session(self.device)
-        if self.FLAGS.experiment_type == "MTAM":
-            self.model = MTAM(self.FLAGS, self.emb, self.sess)
+        # train_process.py:188-204 dispatches the MTAM family by experiment_type ('T_GRU' is
+        # MTAM_only_time_aware_RNN there)
+        members = {"MTAM": family.MTAM, "T_GRU": family.MTAM_only_time_aware_RNN,
+                   "MTAM_no_time_aware_rnn": family.MTAM_no_time_aware_rnn,
+                   "MTAM_via_T_GRU": family.MTAM_via_T_GRU, "MTAM_via_rnn": family.MTAM_via_rnn}
+        if self.FLAGS.experiment_type in members:
+            self.model = members[self.FLAGS.experiment_type](self.FLAGS, self.emb, self.sess)
         elif self.FLAGS.experiment_type in ("Time_Aware_Self_Attention_Model", "PISTRec"):
             # train_process.py:209-210 dispatches Model/attention_baseline_models.py:47-65, the twin of
             # PISTRec's Time_Aware_self_Attention_model (same graph; only the user L2 term differs)

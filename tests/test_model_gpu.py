@@ -35,7 +35,8 @@ def build(tmp_path, B, L, NB, H, items=300, cats=17, users=40, seed=5, id_dist="
         FLAGS.optimizer = optimizer
     cat = SyntheticCatalog(items, cats, users, seed=seed)
     emb = Behavior_embedding_time_aware_attention(True, users, items, cats, L, seed=seed)
-    cls = MTAM if model_name == "MTAM" else Time_Aware_self_Attention_model
+    from mtamrecommender_amd.Model import MTAMRec_model as family
+    cls = Time_Aware_self_Attention_model if model_name == "PISTRec" else getattr(family, model_name)
     model = cls(FLAGS, emb, Session("cuda:0"))
     # make every bias / scale non-trivial so that all gradient paths are exercised
     rng = np.random.default_rng(seed)
@@ -339,3 +340,49 @@ def test_tf_named_npz_round_trip(hip_lib, tmp_path):
     la, _ = model_a.train(model_a.sess, records, 1e-3)
     lb, _ = model_b.train(model_b.sess, rec_b, 1e-3)
     assert abs(la - lb) <= 1e-5 * abs(la)
+
+
+@pytest.mark.parametrize("member", ["MTAM_only_time_aware_RNN", "MTAM_no_time_aware_rnn", "MTAM_via_T_GRU",
+                                    "MTAM_via_rnn"])
+@pytest.mark.parametrize("B,L,NB,H", [(6, 8, 1, 1), (33, 50, 2, 2)])
+def test_mtam_family_forward_and_gradients(hip_lib, tmp_path, member, B, L, NB, H):
+    """The ablation members of Model/MTAMRec_model.py:40-238 that run on the MTAM kernels: logits, loss,
+    every gradient and the clip norm against the oracle."""
+    import oracle.c_oracle as co
+    import oracle.mtam_oracle as O
+    model, FLAGS, records = build(tmp_path, B, L, NB, H, model_name=member)
+    model.use_graph = False
+    p = model.path
+    arrays = {k: v.copy() for k, v in model.get_variables().items()}
+    feed = model.embedding.make_feed_dic_new(records)
+    bt = p.load_feed(feed)
+    p.eval_kernels(bt, 50)
+    logits, pred = bt.logits.cpu().numpy(), bt.pred.cpu().numpy()
+    out, grads, slot_sq = O.loss_and_grads(member, arrays, feed, H, NB, FLAGS.regulation_rate, torch.float64)
+    assert rel(logits, out["logits"].detach().numpy()) < LOGIT_TOL
+    assert np.array_equal(logits, co.score_fma(pred, arrays["embedding_layer/item"]))
+    loss, summary = model.train(model.sess, records, 1e-3)
+    ref_loss = float(out["loss"].detach())
+    assert abs(loss - ref_loss) / abs(ref_loss) < 2e-5
+    got = p.grads_tf()
+    for name, g in grads.items():
+        if g is None:
+            continue
+        assert rel(got[name], g) < GRAD_TOL, name
+    assert set(got) >= {k for k, g in grads.items() if g is not None}
+    ref_norm = O.global_norm(grads, slot_sq, member, True)
+    assert abs(float(p.scale[1]) - ref_norm) / ref_norm < 1e-4
+
+
+def test_mtam_family_trains_through_the_graph(hip_lib, tmp_path):
+    import oracle.mtam_oracle as O
+    B, L, NB, H = 16, 20, 1, 1
+    model, FLAGS, records = build(tmp_path, B, L, NB, H, model_name="MTAM_via_T_GRU")
+    arrays = {k: v.copy() for k, v in model.get_variables().items()}
+    state = O.AdamState(arrays)
+    for step in range(4):                                   # step 3+ replays the captured hipGraph
+        feed = model.embedding.make_feed_dic_new(records)
+        ref = O.train_step("MTAM_via_T_GRU", arrays, state, feed, 1e-3, H, NB, FLAGS.regulation_rate,
+                           FLAGS.max_gradient_norm, True)
+        loss, _ = model.train(model.sess, records, 1e-3)
+        assert abs(loss - ref["loss"]) / abs(ref["loss"]) < 1e-4, step

@@ -167,14 +167,18 @@ def test_padded_slots_have_exactly_zero_upstream_gradient():
         assert np.any(gi[b, sl - 1] != 0)             # the mask-token slot is an attention key
 
 
-def test_finite_differences_float64():
-    feed, arrays = small_case("MTAM", B=3, L=6, D=8, NB=1, H=2)
-    _, grads, _ = O.loss_and_grads("MTAM", arrays, feed, 2, 1, REG, torch.float64)
+FAMILY = ["MTAM", "MTAM_only_time_aware_RNN", "MTAM_no_time_aware_rnn", "MTAM_via_T_GRU", "MTAM_via_rnn"]
+
+
+@pytest.mark.parametrize("model", FAMILY)
+def test_finite_differences_float64(model):
+    feed, arrays = small_case(model, B=3, L=6, D=8, NB=1, H=2)
+    _, grads, _ = O.loss_and_grads(model, arrays, feed, 2, 1, REG, torch.float64)
     rng = np.random.default_rng(0)
 
     def loss_of(a):
         w = O.split_item_table(a, torch.float64, False)
-        return float(O.forward("MTAM", w, O.feed_to_torch(feed, torch.float64), 2, 1, REG)["loss"])
+        return float(O.forward(model, w, O.feed_to_torch(feed, torch.float64), 2, 1, REG)["loss"])
 
     names = [k for k, g in grads.items() if g is not None]
     for name in names:
@@ -294,3 +298,36 @@ def test_slot_optimizers_known_answers():
     ms = 0.5 * 0.9 + 9.0 * 0.1          # sparse form
     assert np.allclose(st.s1["embedding_layer/category"][2], ms, rtol=1e-6)
     assert np.allclose(arrays["embedding_layer/category"][2], 1.0 - 0.3 / np.sqrt(ms + 1e-10), rtol=1e-6)
+
+
+def test_family_members_differ_where_the_reference_says():
+    """Known structure of the ablation members (Model/MTAMRec_model.py:40-238): the plain GRUCell is the
+    time-aware cell with T = 1; without a decoder the prediction is layer_norm(short-term intent); with the
+    GRU outputs as keys, the key at the mask-token slot (t = len-1, a dead GRU step) is the zero vector."""
+    feed, arrays = small_case("MTAM_via_rnn", B=4, L=8, D=16, NB=1, H=2)
+    f = O.feed_to_torch(feed, torch.float64)
+    w = O.split_item_table(arrays, torch.float64, False)
+    out = O.forward("MTAM_via_rnn", w, f, 2, 1, REG)
+    hs = out["hs"].numpy()
+    for b, sl in enumerate(feed["seq_length"]):
+        assert np.all(hs[b, sl - 1:] == 0) and np.any(hs[b, sl - 2] != 0)
+    # plain GRU == time-aware GRU whose time gate is forced to 1 (huge bias b12, zero weights)
+    feed2, arr_t = small_case("MTAM", B=4, L=8, D=16, NB=1, H=2)
+    arr_p = {k.replace("time_aware_gru_cell_decay_new", "gru_cell"): v for k, v in arr_t.items() if "_time_" not in k
+             or "vanilla_attention" in k}
+    for k in list(arr_t):
+        if k.startswith(O.GRU_SCOPE + "_time_"):
+            arr_t[k] = np.zeros_like(arr_t[k])
+    arr_t[O.GRU_SCOPE + "_time_b12"] = np.full_like(arr_t[O.GRU_SCOPE + "_time_b12"], 1e4)
+    f2 = O.feed_to_torch(feed2, torch.float64)
+    a = O.forward("MTAM", O.split_item_table(arr_t, torch.float64, False), f2, 2, 1, REG)
+    b = O.forward("MTAM_no_time_aware_rnn", O.split_item_table(arr_p, torch.float64, False), f2, 2, 1, REG)
+    assert np.abs(a["logits"].numpy() - b["logits"].numpy()).max() < 1e-12
+    # no decoder: pred = layer_norm(short)
+    feed3, arr3 = small_case("MTAM_only_time_aware_RNN", B=4, L=8, D=16, NB=1, H=2)
+    f3 = O.feed_to_torch(feed3, torch.float64)
+    w3 = O.split_item_table(arr3, torch.float64, False)
+    o3 = O.forward("MTAM_only_time_aware_RNN", w3, f3, 2, 1, REG)
+    short = O.gather_indexes(o3["hs"], f3["seq_length"] - 2)
+    want = O.layer_norm(short, w3["ShortTermIntentEncoder/LayerNorm/beta"], w3["ShortTermIntentEncoder/LayerNorm/gamma"])
+    assert np.abs(o3["pred"].numpy() - want.numpy()).max() < 1e-14
