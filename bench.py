@@ -141,6 +141,12 @@ def main():
     global L, NB, H, B_PER_GPU
     L, NB, H, B_PER_GPU = args.seq_len, args.blocks, args.heads, args.batch
 
+    # Only the result line may reach stdout: RCCL prints a version banner to stdout when it creates its
+    # first communicator, and torch / ROCm libraries may print too.  Everything else goes to stderr.
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,14 +157,23 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (see the module docstring)")
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
-    if world > 1:
+    # MTAM_BENCH_FORCE_DP=1: run the multi-GPU code path (RCCL group, gradient exchange, barriers, max over
+    # ranks) with ONE rank -- a rehearsal of the N > 1 launch on a one-GPU box
+    force_dp = world == 1 and os.environ.get("MTAM_BENCH_FORCE_DP", "0") == "1"
+    if force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    use_dist = world > 1 or force_dp
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device(device))
 
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from mtamrecommender_amd import data_parallel, hip_ops as ops
     from mtamrecommender_amd.config.model_parameter import model_parameter
@@ -180,8 +195,8 @@ def main():
                                                   seed=1234)
     model = (MTAM if args.model == "MTAM" else Time_Aware_self_Attention_model)(FLAGS, emb, Session(device))
     p = model.path
-    if world > 1:
-        data_parallel.attach(p, world)
+    if use_dist:
+        data_parallel.attach(p, world, force=force_dp)
         data_parallel.broadcast_parameters(p)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     arrays0 = model.get_variables() if want_cpu else None
@@ -209,17 +224,17 @@ def main():
         if i == 0:
             loss_first = float(bt.loss[0].item())
     log("rank %d: warm-up done" % rank)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         elapsed = data_parallel.max_over_ranks(elapsed, device)
 
     log("rank %d: timed region %.3f s for %d steps" % (rank, elapsed, args.steps))
@@ -254,7 +269,8 @@ def main():
                                       "ml-1m-shaped" if not args.items else "large-catalog", cat.item_count,
                                       cat.category_count, cat.user_count, L, NB, H, B_PER_GPU),
                        "global_batch": B_PER_GPU * world, "seq_len": L, "parallelism": "dp%d" % world,
-                       "id_dist": args.id_dist, "optimizer": "adam", "hipgraph": bool(model.use_graph)},
+                       "id_dist": args.id_dist, "optimizer": "adam", "hipgraph": bool(model.use_graph),
+                       "dp_graph": getattr(model, "_dp_mode", None) if use_dist else None},
             "recall_at_20": recall, "loss_first": loss_first, "loss_last": loss_last,
             "roofline": {"kernel": "emb_gather_kernel", "bound": "hbm", "achieved": gb / t_gather / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / t_gather / 1e9 / HBM_PEAK_GBS,
@@ -268,8 +284,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(batches[:8], FLAGS, arrays0, model_name=args.model)
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
