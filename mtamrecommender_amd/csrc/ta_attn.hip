@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
   __shared__ float sc_s[MAXH][MAXL];
   __shared__ float qk_s[MAXH][MAXL];
   __shared__ float a_s[MAXL], dk_s[MAXL], sg_s[MAXL];
-  __shared__ float o_part[2][D];
+  __shared__ __attribute__((aligned(16))) float o_part[8][D];
   __shared__ float red[4];
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -52,7 +52,31 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
   const int lanes_per_head = 32 / H;
   const float inv_div = sqrtf((float)(D / H));
 
-  if (tid < D) q_s[tid] = p.dec_in[(size_t)b * D + tid];
+  // Every global load that does not depend on the projected query is issued HERE, before the first
+  // barrier: the sample's key / raw-key / value rows (half a wave per row, rows hw, hw+8, ... of the
+  // sample), the key times and time-gate parameters, and the LN parameters.  The kernel is a chain of
+  // short phases on one CU; written phase by phase it paid one global round trip per phase (~9 of them).
+  const int hw = tid >> 5, li = tid & 31;
+  constexpr int KB = 8;                      // keys per half wave and trip: 64 keys per trip of the workgroup
+  const float q_in = (tid < D) ? p.dec_in[(size_t)b * D + tid] : 0.f;
+  const float ln_g = (tid < D) ? p.ln_gamma[tid] : 0.f, ln_b = (tid < D) ? p.ln_beta[tid] : 0.f;
+  const float tq = p.t_query[b];
+  float4 kq[KB], xq[KB], vq[KB];
+  float tk[KB], tp[KB][5];
+  auto load_keys = [&](int jb) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const int jc = min(jb + 8 * i, L - 1);      // clamped: padded keys are valid memory and are masked below
+      kq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.k_off + 4 * li]);
+      vq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.v_off + 4 * li]);
+      xq[i] = *reinterpret_cast<const float4 *>(&p.x[(row0 + jc) * D + 4 * li]);
+      tk[i] = p.t_keys[row0 + jc];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) tp[i][q] = p.tparams[q * L + jc];
+    }
+  };
+  load_keys(hw);
+  if (tid < D) q_s[tid] = q_in;
   __syncthreads();
 
   // [Q | qt] = q . [Wq | Wt]; thread = output column, coalesced weight reads, 16 loads in flight
@@ -76,52 +100,40 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
   }
   __syncthreads();
 
-  // scores: half a wave per key row; the rows of up to KB keys per half wave are loaded before any
-  // of them is reduced, so the key loop is not a chain of exposed global-load latencies
-  {
-    const int hw = tid >> 5, li = tid & 31;
-    const float4 Q4 = *reinterpret_cast<const float4 *>(&Q_s[4 * li]);
-    const float4 T4 = *reinterpret_cast<const float4 *>(&qt_s[4 * li]);
-    const float tq = p.t_query[b];
-    constexpr int KB = 8;
-    for (int jb = hw; jb < L; jb += 8 * KB) {
-      float4 kq[KB], xq[KB];
-      float tk[KB], tp[KB][5];
-      // unconditional loads at a clamped row (padded keys are valid memory and are masked below):
-      // inside `if (j < sl)` every key's loads were waited for before the next key's were issued
+  // scores, masked softmax and the weighted value sum, 64 keys per trip (one trip for L <= 64).  The
+  // value rows stay in registers from the load above until the softmax weights exist; for L > 64 the
+  // softmax needs every score first, so later trips reload (scores in one pass, values in a second).
+  const float4 Q4 = *reinterpret_cast<const float4 *>(&Q_s[4 * li]);
+  const float4 T4 = *reinterpret_cast<const float4 *>(&qt_s[4 * li]);
+  auto score_keys = [&](int jb) {
 #pragma unroll
-      for (int i = 0; i < KB; ++i) {
-        const int jc = min(jb + 8 * i, L - 1);
-        kq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.k_off + 4 * li]);
-        xq[i] = *reinterpret_cast<const float4 *>(&p.x[(row0 + jc) * D + 4 * li]);
-        tk[i] = p.t_keys[row0 + jc];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) tp[i][q] = p.tparams[q * L + jc];
-      }
-#pragma unroll
-      for (int i = 0; i < KB; ++i) {
-        const int j = jb + 8 * i;
-        if (j >= L) break;
-        if (j < sl) {
-          const float dK = group_sum(dot4(kq[i], Q4), lanes_per_head);
-          const float dA = group_sum(dot4(xq[i], T4), 32);
-          const float a = fast_tanh(dA);
-          const float delta = logf(fabsf(tq - tk[i]) + 1.0f);
-          const float dk = fast_tanh(delta * tp[i][0] + tp[i][1]);
-          const float g = tp[i][2] * dk + tp[i][3] * a + tp[i][4];
-          const float sg = fast_sigmoid(g);
-          if ((li % lanes_per_head) == 0) {
-            const int h = li / lanes_per_head;
-            qk_s[h][j] = dK;
-            sc_s[h][j] = (dK * sg) / inv_div;
-          }
-          if (li == 0) { a_s[j] = a; dk_s[j] = dk; sg_s[j] = sg; }
-        } else {
-          if (li < H) { qk_s[li][j] = 0.f; sc_s[li][j] = MASK_VALUE; }
-          if (li == 0) { a_s[j] = 0.f; dk_s[j] = 0.f; sg_s[j] = 0.f; }
+    for (int i = 0; i < KB; ++i) {
+      const int j = jb + 8 * i;
+      if (j >= L) break;
+      if (j < sl) {
+        const float dK = group_sum(dot4(kq[i], Q4), lanes_per_head);
+        const float dA = group_sum(dot4(xq[i], T4), 32);
+        const float a = fast_tanh(dA);
+        const float delta = logf(fabsf(tq - tk[i]) + 1.0f);
+        const float dk = fast_tanh(delta * tp[i][0] + tp[i][1]);
+        const float g = tp[i][2] * dk + tp[i][3] * a + tp[i][4];
+        const float sg = fast_sigmoid(g);
+        if ((li % lanes_per_head) == 0) {
+          const int h = li / lanes_per_head;
+          qk_s[h][j] = dK;
+          sc_s[h][j] = (dK * sg) / inv_div;
         }
+        if (li == 0) { a_s[j] = a; dk_s[j] = dk; sg_s[j] = sg; }
+      } else {
+        if (li < H) { qk_s[li][j] = 0.f; sc_s[li][j] = MASK_VALUE; }
+        if (li == 0) { a_s[j] = 0.f; dk_s[j] = 0.f; sg_s[j] = 0.f; }
       }
     }
+  };
+  score_keys(hw);
+  for (int jb = hw + 8 * KB; jb < L; jb += 8 * KB) {      // L > 64 only
+    load_keys(jb);
+    score_keys(jb);
   }
   __syncthreads();
 
@@ -141,29 +153,36 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
   }
   __syncthreads();
 
-  // O = W . V  (thread = channel, keys split in two halves, 8 value rows in flight)
+  // O = W . V: each half wave sums its own keys (4 channels per lane), the 8 partial rows meet in LDS
   {
-    const int c = tid & (D - 1), part = tid >> 7;
-    const int h = c / (D / H);
-    const int jmid = (sl + 1) / 2;
-    const int j0 = part ? jmid : 0, j1 = part ? sl : jmid;
-    float o = 0.f;
-    for (int jb = j0; jb < j1; jb += 8) {
-      float vv[8];
+    const int head_of_lane = li / lanes_per_head;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add_values = [&](int jb) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) vv[i] = p.kv[(row0 + min(jb + i, L - 1)) * p.ld_kv + p.v_off + c];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (jb + i < j1) o = fmaf(sc_s[h][jb + i], vv[i], o);
+      for (int i = 0; i < KB; ++i) {
+        const int j = jb + 8 * i;
+        if (j < sl) {
+          const float wj = sc_s[head_of_lane][j];
+          o.x = fmaf(wj, vq[i].x, o.x); o.y = fmaf(wj, vq[i].y, o.y);
+          o.z = fmaf(wj, vq[i].z, o.z); o.w = fmaf(wj, vq[i].w, o.w);
+        }
+      }
+    };
+    if (L > 8 * KB) load_keys(hw);             // the first trip's rows were overwritten by later trips
+    add_values(hw);
+    for (int jb = hw + 8 * KB; jb < L; jb += 8 * KB) {
+      load_keys(jb);
+      add_values(jb);
     }
-    o_part[part][c] = o;
+    *reinterpret_cast<float4 *>(&o_part[hw][4 * li]) = o;
   }
   __syncthreads();
 
   // residual + normalize(eps = 1e-8): (y - mean) / sqrt(var + eps) * gamma + beta
   float y = 0.f;
   if (tid < D) {
-    y = o_part[0][tid] + o_part[1][tid] + q_s[tid];
+    y = ((o_part[0][tid] + o_part[1][tid]) + (o_part[2][tid] + o_part[3][tid])) +
+        ((o_part[4][tid] + o_part[5][tid]) + (o_part[6][tid] + o_part[7][tid])) + q_s[tid];
     const float s = wave_sum(y);
     if (lane == 0) red[w] = s;
   }
@@ -180,7 +199,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
     const float var = (red[2] + red[3]) / (float)D;
     const float sd = sqrtf(var + 1e-8f);
     const float xhat = diff / sd;
-    p.dec_out[(size_t)b * D + tid] = p.ln_gamma[tid] * xhat + p.ln_beta[tid];
+    p.dec_out[(size_t)b * D + tid] = ln_g * xhat + ln_b;
     if (p.save) {
       float *sv = p.save + (size_t)b * save_floats(L, H);
       sv[tid] = Q_s[tid];
@@ -237,6 +256,36 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
   const float *sv_qk = sv_sg + L, *sv_w = sv_qk + H * L;
   const float rstd = sv_w[H * L];
 
+  // As in the forward kernel, every global load that depends only on the kernel arguments is issued
+  // before the first barrier: the sample's key / value / raw-key rows (and the running d_x rows when
+  // accumulating), half a wave per row, and each key's gate inputs (thread j = key j).
+  const int hw = tid >> 5, li = tid & 31;
+  const int head_of_lane = li / lanes_per_head;
+  constexpr int KB = 8;
+  float4 kq[KB], vq[KB], xq[KB], ox[KB];
+  auto load_rows = [&](int jb) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const int jc = min(jb + 8 * i, L - 1);
+      kq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.k_off + 4 * li]);
+      vq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.v_off + 4 * li]);
+      xq[i] = *reinterpret_cast<const float4 *>(&p.x[(row0 + jc) * D + 4 * li]);
+    }
+    if (p.accumulate_dx) {              // block-uniform
+#pragma unroll
+      for (int i = 0; i < KB; ++i)
+        ox[i] = *reinterpret_cast<const float4 *>(&p.d_x[(row0 + min(jb + 8 * i, L - 1)) * D + 4 * li]);
+    }
+  };
+  load_rows(hw);
+  const int jg = min(tid, L - 1);      // gate inputs of key `tid` (keys >= 256 are reloaded in the loop below)
+  const float g_sg = sv_sg[jg], g_a = sv_a[jg], g_dk = sv_dk[jg];
+  const float g_tk = p.t_keys[row0 + jg], g_tq = p.t_query[b];
+  const float g_tp2 = p.tparams[2 * L + jg], g_tp3 = p.tparams[3 * L + jg];
+  float g_qk[MAXH];
+#pragma unroll
+  for (int h = 0; h < MAXH; ++h) g_qk[h] = (h < H) ? sv_qk[h * L + jg] : 0.f;
+
   // ---- normalize() backward
   float dxh = 0.f, xhat = 0.f;
   if (tid < D) {
@@ -263,17 +312,11 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
   }
   __syncthreads();
 
-  const int hw = tid >> 5, li = tid & 31;
-  const int head_of_lane = li / lanes_per_head;
-  // ---- dW[h][j] = dO_h . V_j   (value rows of KB keys per half wave loaded before reducing)
-  constexpr int KB = 8;
+  // ---- dW[h][j] = dO_h . V_j   (64 keys per trip; one trip for L <= 64, its rows are already here)
   {
     const float4 dO4 = *reinterpret_cast<const float4 *>(&dO_s[4 * li]);
     for (int jb = hw; jb < L; jb += 8 * KB) {
-      float4 vq[KB];
-#pragma unroll
-      for (int i = 0; i < KB; ++i)      // unconditional, clamped row (see the forward kernel)
-        vq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + min(jb + 8 * i, L - 1)) * p.ld_kv + p.v_off + 4 * li]);
+      if (jb != hw) load_rows(jb);
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
         const int j = jb + 8 * i;
@@ -300,23 +343,27 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
   for (int j = tid; j < L; j += 256) {
     float g_w1 = 0.f, g_b1 = 0.f, g_ow1 = 0.f, g_ow2 = 0.f, g_ob = 0.f, dap = 0.f;
     if (j < sl) {
-      const float sg = sv_sg[j], a = sv_a[j], dk = sv_dk[j];
+      const bool pre = j == tid;                   // always true for L <= 256
+      const float sg = pre ? g_sg : sv_sg[j], a = pre ? g_a : sv_a[j], dk = pre ? g_dk : sv_dk[j];
       float dsg = 0.f;
-      for (int h = 0; h < H; ++h) {
-        const float dS = ds_s[h][j];
-        dsg += dS * sv_qk[h * L + j];
-        ds_s[h][j] = dS * sg / inv_div;            // d(Q_h . K_hj)
+#pragma unroll
+      for (int h = 0; h < MAXH; ++h) {
+        if (h < H) {
+          const float dS = ds_s[h][j];
+          dsg += dS * (pre ? g_qk[h] : sv_qk[h * L + j]);
+          ds_s[h][j] = dS * sg / inv_div;          // d(Q_h . K_hj)
+        }
       }
       dsg = dsg / inv_div;
       const float dG = dsg * sg * (1.f - sg);
-      const float delta = logf(fabsf(p.t_query[b] - p.t_keys[row0 + j]) + 1.0f);
+      const float delta = logf(fabsf(g_tq - (pre ? g_tk : p.t_keys[row0 + j])) + 1.0f);
       g_ow1 = dG * dk;
       g_ow2 = dG * a;
       g_ob = dG;
-      const float ddk = dG * p.tparams[2 * L + j] * (1.f - dk * dk);
+      const float ddk = dG * (pre ? g_tp2 : p.tparams[2 * L + j]) * (1.f - dk * dk);
       g_w1 = ddk * delta;
       g_b1 = ddk;
-      dap = dG * p.tparams[3 * L + j] * (1.f - a * a);
+      dap = dG * (pre ? g_tp3 : p.tparams[3 * L + j]) * (1.f - a * a);
     }
     dap_s[j] = dap;
     float *gp = p.d_tparams_partial + (size_t)b * 5 * L + j;
@@ -331,19 +378,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     float4 aQ = make_float4(0.f, 0.f, 0.f, 0.f), aT = aQ;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int jb = hw; jb < L; jb += 8 * KB) {
-      float4 kq[KB], vq[KB], xq[KB], ox[KB];
-#pragma unroll
-      for (int i = 0; i < KB; ++i) {
-        const int jc = min(jb + 8 * i, L - 1);
-        kq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.k_off + 4 * li]);
-        vq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.v_off + 4 * li]);
-        xq[i] = *reinterpret_cast<const float4 *>(&p.x[(row0 + jc) * D + 4 * li]);
-      }
-      if (p.accumulate_dx) {              // block-uniform
-#pragma unroll
-        for (int i = 0; i < KB; ++i)
-          ox[i] = *reinterpret_cast<const float4 *>(&p.d_x[(row0 + min(jb + 8 * i, L - 1)) * D + 4 * li]);
-      }
+      if (jb != hw || L > 8 * KB) load_rows(jb);       // L <= 64: the rows loaded at the top are still here
 #pragma unroll
       for (int i = 0; i < KB; ++i) {
         const int j = jb + 8 * i;
@@ -394,20 +429,31 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     float dq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[i] = dqp_s[lane + 64 * i];
-    for (int c0 = w; c0 < D; c0 += 4 * 8) {          // 8 rows (32 loads) in flight per wave
-      float wv[8][4];
+    // the wave's 32 weight rows (128 loads) are all in flight before the first one is reduced; the
+    // 32 wave sums run as four batches of eight independent shuffle chains
+    float wv[32][4];
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
+    for (int r = 0; r < 32; ++r)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wv[r][i] = p.wqt[(size_t)(c0 + 4 * r) * (2 * D) + lane + 64 * i];
+      for (int i = 0; i < 4; ++i) wv[r][i] = p.wqt[(size_t)(w + 4 * r) * (2 * D) + lane + 64 * i];
+#pragma unroll
+    for (int r0 = 0; r0 < 32; r0 += 8) {
+      float sv8[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s = fmaf(dq[i], wv[r][i], s);
-        s = wave_sum(s);
-        const int c = c0 + 4 * r;
-        if (lane == 0) p.d_dec_in[(size_t)b * D + c] = s + dO_s[c];
+        for (int i = 0; i < 4; ++i) s = fmaf(dq[i], wv[r0 + r][i], s);
+        sv8[r] = s;
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sv8[r] += __shfl_xor(sv8[r], off, 64);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int c = w + 4 * (r0 + r);
+        if (lane == 0) p.d_dec_in[(size_t)b * D + c] = sv8[r] + dO_s[c];
       }
     }
   }
