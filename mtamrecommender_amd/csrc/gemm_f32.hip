@@ -520,8 +520,15 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumGroup cg) {
   const int r0 = (local / col_blocks) * 64;
   const int r1 = min(q.rows, r0 + 64);
   float s = 0.f;
-  if (c < q.cols)
-    for (int r = r0 + rr; r < r1; r += 4) s += q.in[(size_t)r * q.ld + c];
+  if (c < q.cols) {
+    // the 16 rows of this thread are loaded unconditionally (clamped row, masked value) so that they are
+    // all in flight together instead of one round trip per row
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = q.in[(size_t)min(r0 + rr + 4 * i, q.rows - 1) * q.ld + c];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += (r0 + rr + 4 * i < r1) ? v[i] : 0.f;
+  }
   part[rr][threadIdx.x & 63] = s;
   __syncthreads();
   if (rr == 0 && c < q.cols) {

@@ -96,9 +96,41 @@ __global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restric
   }
   __syncthreads();
   if (!s_last) return;
-  double t = 0.0;
-  for (int i = threadIdx.x; i < n_total; i += 256)
-    t += (double)__hip_atomic_load(partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // The last workgroup sums every partial (and, for the loss, the gather's L2 partials and the per-row
+  // cross entropies).  Loads go out in batches of 8 per thread, unconditionally (clamped index, masked
+  // value): a plain `for (i = tid; i < n; i += 256) t += load(i)` waits out one round trip per iteration
+  // (19 of them for the 4,832 L2 partials: most of this kernel's former 13 us).
+  auto sum_sc1 = [&](const float *src, int n) {
+    double acc = 0.0;
+    for (int base = 0; base < n; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        v[q] = __hip_atomic_load(src + min(base + (int)threadIdx.x + 256 * q, n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += (base + (int)threadIdx.x + 256 * q < n) ? (double)v[q] : 0.0;
+    }
+    return acc;
+  };
+  auto sum_plain = [&](const float *src, int n) {
+    double acc = 0.0;
+    for (int base = 0; base < n; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[min(base + (int)threadIdx.x + 256 * q, n - 1)];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += (base + (int)threadIdx.x + 256 * q < n) ? (double)v[q] : 0.0;
+    }
+    return acc;
+  };
+  double t = sum_sc1(partials, n_total);
+  // the loss inputs were written by earlier kernels of the step: issue their loads before the reduction
+  // of `t` needs a barrier
+  double a_l2 = 0.0, c_ce = 0.0;
+  if (loss) {
+    a_l2 = sum_plain(l2_partial, n_l2);
+    c_ce = sum_plain(ce, B);
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
   if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = t;
@@ -119,9 +151,7 @@ __global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restric
   if (loss) {
     // step epilogue: the reported loss (Model/base_model.py:322-326) from the per-row cross entropies
     // and the gather's L2 partials -- both written by earlier kernels of the step
-    double a = 0.0, c = 0.0;
-    for (int i = threadIdx.x; i < n_l2; i += 256) a += (double)l2_partial[i];
-    for (int i = threadIdx.x; i < B; i += 256) c += (double)ce[i];
+    double a = a_l2, c = c_ce;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       a += __shfl_xor(a, off, 64);
