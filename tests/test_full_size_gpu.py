@@ -4,6 +4,7 @@
       float64 oracle.
   C3  PISTRec, 1,000,000 items, L=100, B=128: logits / loss / gradients vs the float32 oracle (the
       oracle finishes a step in seconds at this size), top-K bit-exact vs the k-ordered fmaf chain.
+  C5  shape only (50,000,000 items, L=200) in fp32 -- bf16 storage is not built: properties as for C4.
   C4  MTAM, 10,000,000 items: the oracle no longer finishes in seconds, so size-independent
       properties of the HIP path: gathered rows are bit-exact table rows, top-K lists are sorted,
       tie-ordered and complete (nothing outside the list beats its last entry), the softmax
@@ -134,4 +135,43 @@ def test_c4_mtam_10m_items_properties(hip_lib, tmp_path):
     losses = [loss0]
     for s in range(4):
         losses.append(model.train(model.sess, records[:B], 1e-3)[0])
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+@pytest.mark.skipif(__import__("os").environ.get("MTAM_SKIP_C5", "0") == "1",
+                    reason="C5 shape (50 M items, L=200): ~130 GB of HBM, ~50 GB of host memory, 25 s")
+def test_c5_shape_fp32_50m_items_l200(hip_lib, tmp_path):
+    """BASELINE.json configs[4] asks for bf16 storage, which is not built; this runs the same SHAPE in fp32
+    (it fits one GPU) to check that nothing in the path breaks past 2^31 elements: exact gathers, sorted and
+    complete top-K lists, zero-sum softmax gradient rows, a falling loss."""
+    from mtamrecommender_amd.config.model_parameter import model_parameter
+    from mtamrecommender_amd.Embedding.Behavior_embedding_time_aware_attention import \
+        Behavior_embedding_time_aware_attention
+    from mtamrecommender_amd.Model.MTAMRec_model import MTAM
+    from mtamrecommender_amd.Model.base_model import Session
+    from mtamrecommender_amd.data.synthetic import SyntheticCatalog, make_records
+    B, L, V_items = 128, 200, 50000000
+    FLAGS = model_parameter().get_parameter("MTAMb1_movielen").FLAGS
+    FLAGS.num_blocks, FLAGS.num_heads, FLAGS.length_of_user_history = 1, 1, L
+    FLAGS.checkpoint_path_dir = str(tmp_path)
+    cat = SyntheticCatalog(V_items, 1000, 4832, seed=5)
+    emb = Behavior_embedding_time_aware_attention(True, 4832, V_items, 1000, L, seed=5)
+    model = MTAM(FLAGS, emb, Session("cuda:0"))
+    model.use_graph = False
+    p = model.path
+    records = make_records(cat, B, L, seed=6)
+    feed = emb.make_feed_dic_new(records)
+    bt = p.load_feed(feed)
+    p.eval_kernels(bt, 50)
+    item_ids = torch.from_numpy(feed["item_list"].astype(np.int64)).cuda().view(-1)
+    assert torch.equal(bt.ic[:, :128], p.tables["item"][item_ids])
+    top = bt.topk_idx.long()
+    vals = torch.gather(bt.logits, 1, top)
+    assert bool((vals[:, :-1] >= vals[:, 1:]).all())
+    kth = vals[:, -1:]
+    assert bool(((bt.logits > kth).sum(1) <= 49).all()) and bool(((bt.logits >= kth).sum(1) >= 50).all())
+    # the highest table rows are reachable: the last row's score equals a direct dot product
+    last = (bt.pred.double() @ p.tables["item"][-1].double())
+    assert float((bt.logits[:, -1].double() - last).abs().max()) < 1e-4
+    losses = [model.train(model.sess, records, 1e-3)[0] for _ in range(3)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
