@@ -93,7 +93,9 @@ class SelfAttentionPath(TimeAwarePath):
                      aux_out=part[self.nb_dense:])
         else:
             ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
-        split_v = max(1, min(64, (self.item_rows + 127) // 128))
+        # split-K over the catalog: ~64 slices at ml-1m sizes; for large catalogs enough slices (<= 1024) that
+        # 2,000+ workgroups stream the table (64 slices left one workgroup per CU: 43 TFLOP/s at V = 1 M)
+        split_v = max(1, min(64, (self.item_rows + 127) // 128), min(1024, self.item_rows // 2048))
         ops.gemm(bt.logits, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v)
         ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_long, gseg("head/ln"))
         d_out, d_in = bt.d_a, bt.d_b

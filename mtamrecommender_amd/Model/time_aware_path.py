@@ -273,7 +273,9 @@ class TimeAwarePath(object):
         else:
             ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
         # d_pred = G E -> head LN -> decoder blocks (last to first)
-        split_v = max(1, min(64, (self.item_rows + 127) // 128))
+        # split-K over the catalog: ~64 slices at ml-1m sizes; for large catalogs enough slices (<= 1024) that
+        # 2,000+ workgroups stream the table (64 slices left one workgroup per CU: 43 TFLOP/s at V = 1 M)
+        split_v = max(1, min(64, (self.item_rows + 127) // 128), min(1024, self.item_rows // 2048))
         ops.gemm(bt.logits, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v)
         keys = bt.hs if cfg["keys"] == "gru" else bt.x
         d_keys = bt.d_hs if cfg["keys"] == "gru" else bt.d_x      # gradient of user_history
