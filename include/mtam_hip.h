@@ -113,6 +113,10 @@ typedef struct {
   float *out;
 } MtamColsumJob;
 int mtam_colsum_atomic_multi(int n, const MtamColsumJob *jobs, void *stream);
+/* mtam_gemm_tn_atomic_grouped + mtam_colsum_atomic_multi in ONE launch: every kernel gradient and every
+ * bias-like gradient of a training step (Model/base_model.py:292).  Both arrays are HOST arrays. */
+int mtam_weight_grads(int n_gemm, const MtamGemmDesc *d, int n_colsum, const MtamColsumJob *jobs,
+                      void *stream);
 
 /* --------------------------------------------------------- embedding gather
  * tf.nn.embedding_lookup x4 (Embedding/Behavior_embedding_time_aware_attention.py:68,75,82,90)

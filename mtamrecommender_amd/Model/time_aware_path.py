@@ -327,10 +327,12 @@ class TimeAwarePath(object):
                  bias=bt.d_xt, aux_in=bt.zr, aux_out=bt.d_z)
         ops.gemm(bt.d_z, self.seg("dense4emb/w"), bt.d_ic, trans_b=True)
         problems.append(prob(bt.ic, 2 * D, bt.d_z, D, "dense4emb/w", 2 * D, D, R, sr))
-        # every weight gradient in ONE grouped launch, every bias-like one in ONE launch
-        for chunk in _chunks(problems, MAX_GROUP):
+        # every weight gradient and every bias-like gradient in ONE launch (more when a group overflows)
+        pc, jc = list(_chunks(problems, MAX_GROUP)), list(_chunks(jobs, MAX_GROUP))
+        ops.weight_grads(pc[0], jc[0])
+        for chunk in pc[1:]:
             ops.gemm_tn_atomic_grouped(chunk)
-        for chunk in _chunks(jobs, MAX_GROUP):
+        for chunk in jc[1:]:
             ops.colsum_atomic_multi(chunk)
         # tables: sparse rows on top of the dense item gradient
         slot_part = part[self.nb_dense + self.nb_item:]

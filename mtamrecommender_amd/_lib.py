@@ -63,6 +63,7 @@ SIGNATURES = {
     "mtam_opt_update": (c_int, [c_int, P, P, P, P, c_size_t, P, P, c_size_t, c_size_t, P]),
     "mtam_gemm_tn_atomic_grouped": (c_int, [c_int, P, P]),
     "mtam_colsum_atomic_multi": (c_int, [c_int, P, P]),
+    "mtam_weight_grads": (c_int, [c_int, P, c_int, P, P]),
 }
 
 

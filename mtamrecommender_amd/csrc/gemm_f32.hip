@@ -331,6 +331,65 @@ struct GroupArgs {
   int n;
 };
 
+// 64 rows x 64 columns of one column-sum job: out[c] += sum over the rows of in[r][c]
+__device__ __forceinline__ void colsum_block(const MtamColsumJob &q, int local, float (*part)[64]) {
+  const int col_blocks = (q.cols + 63) / 64;
+  const int c = (local % col_blocks) * 64 + (threadIdx.x & 63);
+  const int rr = threadIdx.x >> 6;
+  const int r0 = (local / col_blocks) * 64;
+  const int r1 = min(q.rows, r0 + 64);
+  float s = 0.f;
+  if (c < q.cols) {
+    // the 16 rows of this thread are loaded unconditionally (clamped row, masked value) so that they are
+    // all in flight together instead of one round trip per row
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = q.in[(size_t)min(r0 + rr + 4 * i, q.rows - 1) * q.ld + c];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += (r0 + rr + 4 * i < r1) ? v[i] : 0.f;
+  }
+  part[rr][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rr == 0 && c < q.cols) {
+    s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    atomicAdd(q.out + c, s);
+  }
+}
+
+struct ColsumGroup {
+  MtamColsumJob j[MTAM_MAX_GROUP];
+  int first[MTAM_MAX_GROUP + 1];
+  int n;
+};
+
+// Every weight gradient (grouped C += A^T B) AND every bias-like gradient (column sums) of the step in
+// ONE launch: workgroups [0, gemm_blocks) walk the GEMM (tile, k-slice) units, the rest the column-sum
+// blocks.  tf.gradients w.r.t. kernels and biases, Model/base_model.py:292.
+struct WeightGradArgs {
+  GroupArgs g;
+  ColsumGroup c;
+  int gemm_blocks;
+};
+
+__global__ __launch_bounds__(256) void weight_grads_kernel(WeightGradArgs wa) {
+  __shared__ __attribute__((aligned(16))) float As[2 * TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * TILE_FLOATS];
+  if ((int)blockIdx.x >= wa.gemm_blocks) {
+    const int bid = blockIdx.x - wa.gemm_blocks;
+    int j = 0;
+    while (j + 1 < wa.c.n && bid >= wa.c.first[j + 1]) ++j;
+    colsum_block(wa.c.j[j], bid - wa.c.first[j], reinterpret_cast<float (*)[64]>(As));
+    return;
+  }
+  const GroupArgs &ga = wa.g;
+  int g = 0;
+  while (g + 1 < ga.n && (int)blockIdx.x >= ga.first[g + 1]) ++g;
+  const GemmArgs &p = ga.g[g];
+  const int local = blockIdx.x - ga.first[g];
+  const int tiles = p.tiles_n * ((p.M + BM - 1) / BM);
+  gemm_tile<true, false, MTAM_EPI_ATOMIC>(p, As, Bs, local % tiles, local / tiles);
+}
+
 __global__ __launch_bounds__(256) void gemm_tn_atomic_grouped_kernel(GroupArgs ga) {
   __shared__ __attribute__((aligned(16))) float As[2 * TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float Bs[2 * TILE_FLOATS];
@@ -440,9 +499,8 @@ extern "C" int mtam_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int
   return MTAM_OK;
 }
 
-extern "C" int mtam_gemm_tn_atomic_grouped(int n, const MtamGemmDesc *d, void *stream) {
+static int fill_group(int n, const MtamGemmDesc *d, GroupArgs &ga, int &blocks_out) {
   MTAM_CHECK_ARG(n >= 1 && n <= MTAM_MAX_GROUP && d, "gemm_grouped: 1 <= n <= %d problems", MTAM_MAX_GROUP);
-  GroupArgs ga;
   ga.n = n;
   int blocks = 0;
   for (int i = 0; i < n; ++i) {
@@ -466,8 +524,47 @@ extern "C" int mtam_gemm_tn_atomic_grouped(int n, const MtamGemmDesc *d, void *s
     blocks += a.tiles_n * ((q.M + BM - 1) / BM) * split;
   }
   ga.first[n] = blocks;
+  blocks_out = blocks;
+  return MTAM_OK;
+}
+
+static int fill_colsums(int n, const MtamColsumJob *jobs, ColsumGroup &cg, int &blocks_out) {
+  MTAM_CHECK_ARG(n >= 1 && n <= MTAM_MAX_GROUP && jobs, "colsum_multi: 1 <= n <= %d jobs", MTAM_MAX_GROUP);
+  cg.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const MtamColsumJob &q = jobs[i];
+    MTAM_CHECK_ARG(q.in && q.out && q.rows > 0 && q.cols > 0 && q.ld >= q.cols, "colsum_multi[%d]: bad job", i);
+    cg.j[i] = q;
+    cg.first[i] = blocks;
+    blocks += ((q.cols + 63) / 64) * ((q.rows + 63) / 64);
+  }
+  cg.first[n] = blocks;
+  blocks_out = blocks;
+  return MTAM_OK;
+}
+
+extern "C" int mtam_gemm_tn_atomic_grouped(int n, const MtamGemmDesc *d, void *stream) {
+  GroupArgs ga;
+  int blocks = 0;
+  const int rc = fill_group(n, d, ga, blocks);
+  if (rc) return rc;
   hipLaunchKernelGGL(gemm_tn_atomic_grouped_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), ga);
   MTAM_CHECK_LAUNCH("gemm_grouped");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_weight_grads(int n_gemm, const MtamGemmDesc *d, int n_colsum, const MtamColsumJob *jobs,
+                                 void *stream) {
+  WeightGradArgs wa;
+  int gb = 0, cb = 0;
+  int rc = fill_group(n_gemm, d, wa.g, gb);
+  if (rc) return rc;
+  rc = fill_colsums(n_colsum, jobs, wa.c, cb);
+  if (rc) return rc;
+  wa.gemm_blocks = gb;
+  hipLaunchKernelGGL(weight_grads_kernel, dim3(gb + cb), dim3(256), 0, static_cast<hipStream_t>(stream), wa);
+  MTAM_CHECK_LAUNCH("weight_grads");
   return MTAM_OK;
 }
 
@@ -503,54 +600,19 @@ extern "C" int mtam_colsum_atomic(const float *in, int rows, int cols, int ld, f
 }
 
 namespace {
-struct ColsumGroup {
-  MtamColsumJob j[MTAM_MAX_GROUP];
-  int first[MTAM_MAX_GROUP + 1];
-  int n;
-};
 __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumGroup cg) {
   __shared__ float part[4][64];
   int g = 0;
   while (g + 1 < cg.n && (int)blockIdx.x >= cg.first[g + 1]) ++g;
-  const MtamColsumJob &q = cg.j[g];
-  const int local = blockIdx.x - cg.first[g];
-  const int col_blocks = (q.cols + 63) / 64;
-  const int c = (local % col_blocks) * 64 + (threadIdx.x & 63);
-  const int rr = threadIdx.x >> 6;
-  const int r0 = (local / col_blocks) * 64;
-  const int r1 = min(q.rows, r0 + 64);
-  float s = 0.f;
-  if (c < q.cols) {
-    // the 16 rows of this thread are loaded unconditionally (clamped row, masked value) so that they are
-    // all in flight together instead of one round trip per row
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = q.in[(size_t)min(r0 + rr + 4 * i, q.rows - 1) * q.ld + c];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += (r0 + rr + 4 * i < r1) ? v[i] : 0.f;
-  }
-  part[rr][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rr == 0 && c < q.cols) {
-    s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-    atomicAdd(q.out + c, s);
-  }
+  colsum_block(cg.j[g], blockIdx.x - cg.first[g], part);
 }
 }  // namespace
 
 extern "C" int mtam_colsum_atomic_multi(int n, const MtamColsumJob *jobs, void *stream) {
-  MTAM_CHECK_ARG(n >= 1 && n <= MTAM_MAX_GROUP && jobs, "colsum_multi: 1 <= n <= %d jobs", MTAM_MAX_GROUP);
   ColsumGroup cg;
-  cg.n = n;
   int blocks = 0;
-  for (int i = 0; i < n; ++i) {
-    const MtamColsumJob &q = jobs[i];
-    MTAM_CHECK_ARG(q.in && q.out && q.rows > 0 && q.cols > 0 && q.ld >= q.cols, "colsum_multi[%d]: bad job", i);
-    cg.j[i] = q;
-    cg.first[i] = blocks;
-    blocks += ((q.cols + 63) / 64) * ((q.rows + 63) / 64);
-  }
-  cg.first[n] = blocks;
+  const int rc = fill_colsums(n, jobs, cg, blocks);
+  if (rc) return rc;
   hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cg);
   MTAM_CHECK_LAUNCH("colsum_multi");
   return MTAM_OK;

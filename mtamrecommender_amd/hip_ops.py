@@ -274,14 +274,26 @@ def opt_update(kind, p, slot1, slot2, g, n, scale, lr, sparse_begin, rowskip_end
                                    int(sparse_begin), int(rowskip_end), _stream()), "mtam_opt_update")
 
 
-def gemm_tn_atomic_grouped(problems):
-    """problems: list of dicts(A, lda, B, ldb, C, ldc, M, N, K, split_k) with device tensors."""
-    lib = _lib.load()
+def _gemm_descs(problems):
     arr = (_lib.GemmDesc * len(problems))()
     for d, q in zip(arr, problems):
         d.A, d.B, d.C = _p(q["A"]).value, _p(q["B"]).value, _p(q["C"]).value
         d.lda, d.ldb, d.ldc = q["lda"], q["ldb"], q["ldc"]
         d.M, d.N, d.K, d.split_k = q["M"], q["N"], q["K"], q.get("split_k", 1)
+    return arr
+
+
+def _colsum_jobs(jobs):
+    arr = (_lib.ColsumJob * len(jobs))()
+    for d, (x, rows, cols, ld, out) in zip(arr, jobs):
+        d.in_, d.rows, d.cols, d.ld, d.out = _p(x).value, rows, cols, ld, _p(out).value
+    return arr
+
+
+def gemm_tn_atomic_grouped(problems):
+    """problems: list of dicts(A, lda, B, ldb, C, ldc, M, N, K, split_k) with device tensors."""
+    lib = _lib.load()
+    arr = _gemm_descs(problems)
     _lib.check(lib.mtam_gemm_tn_atomic_grouped(len(problems), ctypes.byref(arr), _stream()),
                "mtam_gemm_tn_atomic_grouped")
 
@@ -289,8 +301,14 @@ def gemm_tn_atomic_grouped(problems):
 def colsum_atomic_multi(jobs):
     """jobs: list of (in_tensor, rows, cols, ld, out_tensor)."""
     lib = _lib.load()
-    arr = (_lib.ColsumJob * len(jobs))()
-    for d, (x, rows, cols, ld, out) in zip(arr, jobs):
-        d.in_, d.rows, d.cols, d.ld, d.out = _p(x).value, rows, cols, ld, _p(out).value
+    arr = _colsum_jobs(jobs)
     _lib.check(lib.mtam_colsum_atomic_multi(len(jobs), ctypes.byref(arr), _stream()),
                "mtam_colsum_atomic_multi")
+
+
+def weight_grads(problems, jobs):
+    """Both of the above in one launch."""
+    lib = _lib.load()
+    a, b = _gemm_descs(problems), _colsum_jobs(jobs)
+    _lib.check(lib.mtam_weight_grads(len(problems), ctypes.byref(a), len(jobs), ctypes.byref(b), _stream()),
+               "mtam_weight_grads")
