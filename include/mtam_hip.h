@@ -223,19 +223,27 @@ int mtam_tagru_bwd(const float *d_short, const float *d_hs, const float *x, cons
  *   ln_beta, ln_gamma [D]
  *   dec_out [B, D]
  *   save [B, mtam_ta_attn_decode_save_floats(L, H)] or NULL
+ *   head_beta, head_gamma [D], pred_out [B, D], head_save [B, D+1] (or all NULL): the model's head
+ *   layer_norm (tf.contrib.layers.layer_norm, eps 1e-12, Model/MTAMRec_model.py:91) applied to the LAST
+ *   block's output in the same launch; head_save has mtam_layer_norm_fwd's layout (x_hat | rstd).
  */
 int mtam_ta_attn_decode_save_floats(int L, int H);
 int mtam_ta_attn_decode_fwd(const float *dec_in, const float *x, const float *kv, int ld_kv,
                             int k_off, int v_off, const float *t_query, const float *t_keys,
                             const int32_t *seq_len, const float *wqt, const float *bq,
                             const float *tparams, const float *ln_beta, const float *ln_gamma,
-                            int B, int L, int H, float *dec_out, float *save, void *stream);
+                            int B, int L, int H, float *dec_out, float *save,
+                            const float *head_beta, const float *head_gamma, float *pred_out,
+                            float *head_save, void *stream);
 
 /*   d_out [B, D] gradient of dec_out
  *   d_dec_in [B, D] out;  d_kv [B*L, ld_kv] out at k_off / v_off (pre-activation
  *   gradients, relu mask applied);  d_x [B*L, D]: = or += (accumulate_dx) the
  *   raw-key path;  d_qt_pre [B, 2D] out: d(Q pre-act) | d(q @ Wt)
  *   d_tparams_partial [B, 5, L], d_ln_partial [B, 2, D] (beta | gamma): per sample
+ *   d_pred [B, D], head_gamma [D], head_save [B, D+1], d_head_partial [B, 2, D] (or all NULL): backward
+ *   of the fused head layer_norm; with d_pred given, d_out is not read (may be NULL) and
+ *   d_head_partial receives the per-sample d beta | d gamma of the head LN.
  */
 int mtam_ta_attn_decode_bwd(const float *d_out, const float *dec_in, const float *x,
                             const float *kv, int ld_kv, int k_off, int v_off,
@@ -243,7 +251,9 @@ int mtam_ta_attn_decode_bwd(const float *d_out, const float *dec_in, const float
                             const float *wqt, const float *tparams, const float *ln_gamma,
                             const float *save, int B, int L, int H, int accumulate_dx,
                             float *d_dec_in, float *d_kv, float *d_x, float *d_qt_pre,
-                            float *d_tparams_partial, float *d_ln_partial, void *stream);
+                            float *d_tparams_partial, float *d_ln_partial,
+                            const float *d_pred, const float *head_gamma, const float *head_save,
+                            float *d_head_partial, void *stream);
 
 /* ------------------------------------------------------------- layer norm
  * y = LN(x [+ resid]) over the last dimension (D = 128), two forms:

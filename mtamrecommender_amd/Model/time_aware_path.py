@@ -105,6 +105,7 @@ class _Batch(object):
             self.d_x = self.d_clear[B * D:].view(R, D)
             self.d_hs = f(R, D)
         self.d_short = f(B, D)
+        self.d_head_partial = f(B, 2 * D)
         self.n_slot = ops.emb_scatter_partials(B, L)
         self.norm_partial = torch.zeros(path.nb_all + self.n_slot, dtype=torch.float32, device=dev)
         self.topk_idx = torch.zeros((B, 50), dtype=torch.int32, device=dev)
@@ -235,18 +236,19 @@ class TimeAwarePath(object):
             ops.layer_norm_fwd(bt.short, sl[0], sl[1], 1e-12, B, bt.short_n, bt.short_ln_save if training else None)
         if cfg["attention"] and cfg["keys"] == "gru":
             ops.gemm(bt.hs, self.seg("kv/w"), bt.kv, epilogue=ops.EPI_BIAS_RELU, bias=self.seg("kv/b"))
-        last = bt.short
+        hl = self.seg("head/ln")
         if cfg["attention"]:
             for i in range(NB):
                 ln = self.seg("blk%d/ln" % i)
+                # the last block also applies the head layer_norm (pred) in the same launch
+                head = (hl[0], hl[1], bt.pred, bt.ln_save if training else None) if i == NB - 1 else None
                 ops.ta_attn_decode_fwd(bt.dec[i], keys, bt.kv, 2 * NB * D, 2 * i * D, (2 * i + 1) * D,
                                        fd["target_item_time"], fd["time_list"], fd["seq_length"],
                                        self.seg("blk%d/wqt" % i), self.seg("blk%d/bq" % i),
                                        self.seg("blk%d/tparams" % i), ln[0], ln[1], B, L, H, bt.dec[i + 1],
-                                       bt.attn_save[i] if training else None)
-            last = bt.dec[NB]
-        hl = self.seg("head/ln")
-        ops.layer_norm_fwd(last, hl[0], hl[1], 1e-12, B, bt.pred, bt.ln_save if training else None)
+                                       bt.attn_save[i] if training else None, head=head)
+        else:
+            ops.layer_norm_fwd(bt.short, hl[0], hl[1], 1e-12, B, bt.pred, bt.ln_save if training else None)
         ops.gemm(bt.pred, T["item"], bt.logits, trans_b=True)
 
     def loss_and_logit_grad(self, bt):
@@ -281,15 +283,17 @@ class TimeAwarePath(object):
         d_keys = bt.d_hs if cfg["keys"] == "gru" else bt.d_x      # gradient of user_history
         problems, jobs = [], []
         if cfg["attention"]:
-            ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_dec[NB], gseg("head/ln"))
             for i in reversed(range(NB)):
                 ln = self.seg("blk%d/ln" % i)
-                ops.ta_attn_decode_bwd(bt.d_dec[i + 1], bt.dec[i], keys, bt.kv, 2 * NB * D, 2 * i * D,
-                                       (2 * i + 1) * D, fd["target_item_time"], fd["time_list"],
+                # the last block starts from d_pred: backward of the fused head layer_norm
+                head = (bt.d_pred, self.seg("head/ln")[1], bt.ln_save, bt.d_head_partial) if i == NB - 1 else None
+                ops.ta_attn_decode_bwd(None if head else bt.d_dec[i + 1], bt.dec[i], keys, bt.kv, 2 * NB * D,
+                                       2 * i * D, (2 * i + 1) * D, fd["target_item_time"], fd["time_list"],
                                        fd["seq_length"], self.seg("blk%d/wqt" % i), self.seg("blk%d/tparams" % i),
                                        ln[1], bt.attn_save[i], B, L, H, 0 if i == NB - 1 else 1,
                                        bt.d_dec[i], bt.d_kv, d_keys, bt.d_qt[i], bt.d_tp_partial[i],
-                                       bt.d_ln_partial[i])
+                                       bt.d_ln_partial[i], head=head)
+            jobs.append((bt.d_head_partial, B, 2 * D, 2 * D, gseg("head/ln").view(-1)))
             problems += [prob(keys, D, bt.d_kv, 2 * NB * D, "kv/w", D, 2 * NB * D, R, sr)] + \
                 [prob(bt.dec[i], D, bt.d_qt[i], 2 * D, "blk%d/wqt" % i, D, 2 * D, B, 1) for i in range(NB)]
             jobs += [(bt.d_kv, R, 2 * NB * D, 2 * NB * D, gseg("kv/b"))]

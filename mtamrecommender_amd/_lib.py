@@ -37,9 +37,9 @@ SIGNATURES = {
     "mtam_tagru_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
     "mtam_ta_attn_decode_save_floats": (c_int, [c_int, c_int]),
     "mtam_ta_attn_decode_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
-                                        c_int, c_int, c_int, P, P, P]),
+                                        c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "mtam_ta_attn_decode_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P,
-                                        c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
+                                        c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "mtam_layer_norm_fwd": (c_int, [P, P, P, P, c_float, c_int, c_int, P, P, P]),
     "mtam_ta_selfattn_gate_softmax_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P]),
     "mtam_ta_selfattn_gate_softmax_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P]),

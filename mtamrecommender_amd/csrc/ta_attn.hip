@@ -29,6 +29,10 @@ struct FwdArgs {
   const float *wqt, *bq, *tparams, *ln_beta, *ln_gamma;
   int B, L, H;
   float *dec_out, *save;
+  // optional (last decoder block): the model's head layer_norm (tf.contrib.layers.layer_norm, eps 1e-12,
+  // Model/MTAMRec_model.py:91) applied to this block's output in the same launch
+  const float *head_beta, *head_gamma;
+  float *pred_out, *head_save;
 };
 
 __device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
@@ -195,11 +199,13 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
     if (lane == 0) red[2 + w] = s;
   }
   __syncthreads();
+  float out = 0.f;
   if (tid < D) {
     const float var = (red[2] + red[3]) / (float)D;
     const float sd = sqrtf(var + 1e-8f);
     const float xhat = diff / sd;
-    p.dec_out[(size_t)b * D + tid] = ln_g * xhat + ln_b;
+    out = ln_g * xhat + ln_b;
+    p.dec_out[(size_t)b * D + tid] = out;
     if (p.save) {
       float *sv = p.save + (size_t)b * save_floats(L, H);
       sv[tid] = Q_s[tid];
@@ -221,6 +227,32 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
       sv[3 * L + H * L + i] = sc_s[h][j];
     }
   }
+  if (p.pred_out) {                    // block-uniform: fused head layer_norm
+    __syncthreads();                   // red[] is reused
+    if (tid < D) {
+      const float s1 = wave_sum(out);
+      if (lane == 0) red[w] = s1;
+    }
+    __syncthreads();
+    float d2 = 0.f, mean2 = 0.f;
+    if (tid < D) {
+      mean2 = (red[0] + red[1]) / (float)D;
+      d2 = out - mean2;
+      const float s2 = wave_sum(d2 * d2);
+      if (lane == 0) red[2 + w] = s2;
+    }
+    __syncthreads();
+    if (tid < D) {
+      const float var2 = (red[2] + red[3]) / (float)D;
+      const float rstd2 = 1.0f / sqrtf(var2 + 1e-12f);
+      const float inv = rstd2 * p.head_gamma[tid];
+      p.pred_out[(size_t)b * D + tid] = out * inv + (p.head_beta[tid] - mean2 * inv);
+      if (p.head_save) {
+        p.head_save[(size_t)b * (D + 1) + tid] = d2 * rstd2;
+        if (tid == 0) p.head_save[(size_t)b * (D + 1) + D] = rstd2;
+      }
+    }
+  }
 }
 
 struct BwdArgs {
@@ -231,6 +263,10 @@ struct BwdArgs {
   const float *wqt, *tparams, *ln_gamma, *save;
   int B, L, H, accumulate_dx;
   float *d_dec_in, *d_kv, *d_x, *d_qt_pre, *d_tparams_partial, *d_ln_partial;
+  // optional (last decoder block): backward of the fused head layer_norm -- d_out is then NOT read;
+  // the gradient of the block output is derived from d_pred here
+  const float *d_pred, *head_gamma, *head_save;
+  float *d_head_partial;      // [B, 2D]: per-sample d beta | d gamma (caller column-sums)
 };
 
 __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
@@ -286,10 +322,30 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
 #pragma unroll
   for (int h = 0; h < MAXH; ++h) g_qk[h] = (h < H) ? sv_qk[h * L + jg] : 0.f;
 
+  // ---- fused head layer_norm backward (last block only): dy = rstd * (a - mean(a) - h * mean(a h)), a = d_pred * gamma
+  float dy_head = 0.f;
+  if (p.d_pred) {                      // block-uniform
+    float a = 0.f, hh = 0.f;
+    if (tid < D) {
+      const float yp = p.d_pred[(size_t)b * D + tid];
+      hh = p.head_save[(size_t)b * (D + 1) + tid];
+      a = yp * p.head_gamma[tid];
+      p.d_head_partial[((size_t)b * 2 + 0) * D + tid] = yp;
+      p.d_head_partial[((size_t)b * 2 + 1) * D + tid] = yp * hh;
+      const float s1 = wave_sum(a), s2 = wave_sum(a * hh);
+      if (lane == 0) { red[w] = s1; red[2 + w] = s2; }
+    }
+    __syncthreads();
+    if (tid < D) {
+      const float m1 = (red[0] + red[1]) / (float)D, m2 = (red[2] + red[3]) / (float)D;
+      dy_head = p.head_save[(size_t)b * (D + 1) + D] * (a - m1 - hh * m2);
+    }
+    __syncthreads();                   // red[] is reused below
+  }
   // ---- normalize() backward
   float dxh = 0.f, xhat = 0.f;
   if (tid < D) {
-    const float dy = p.d_out[(size_t)b * D + tid];
+    const float dy = p.d_pred ? dy_head : p.d_out[(size_t)b * D + tid];
     xhat = sv[2 * D + tid];
     p.d_ln_partial[((size_t)b * 2 + 0) * D + tid] = dy;
     p.d_ln_partial[((size_t)b * 2 + 1) * D + tid] = dy * xhat;
@@ -477,14 +533,17 @@ extern "C" int mtam_ta_attn_decode_fwd(const float *dec_in, const float *x, cons
                                        int k_off, int v_off, const float *t_query, const float *t_keys,
                                        const int32_t *seq_len, const float *wqt, const float *bq,
                                        const float *tparams, const float *ln_beta, const float *ln_gamma,
-                                       int B, int L, int H, float *dec_out, float *save, void *stream) {
+                                       int B, int L, int H, float *dec_out, float *save, const float *head_beta,
+                                       const float *head_gamma, float *pred_out, float *head_save,
+                                       void *stream) {
   MTAM_CHECK_ARG(dec_in && x && kv && t_query && t_keys && seq_len && wqt && bq && tparams && ln_beta &&
                      ln_gamma && dec_out,
                  "ta_attn_decode_fwd: null argument");
+  MTAM_CHECK_ARG(!pred_out || (head_beta && head_gamma), "ta_attn_decode_fwd: pred_out needs the head LN parameters");
   int rc = check_attn_common("ta_attn_decode_fwd", B, L, H, ld_kv, k_off, v_off, kv, x);
   if (rc) return rc;
   FwdArgs a{dec_in, x, kv, ld_kv, k_off, v_off, t_query, t_keys, seq_len, wqt, bq, tparams,
-            ln_beta, ln_gamma, B, L, H, dec_out, save};
+            ln_beta, ln_gamma, B, L, H, dec_out, save, head_beta, head_gamma, pred_out, head_save};
   hipLaunchKernelGGL(ta_attn_decode_fwd_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("ta_attn_decode_fwd");
   return MTAM_OK;
@@ -496,15 +555,20 @@ extern "C" int mtam_ta_attn_decode_bwd(const float *d_out, const float *dec_in, 
                                        const float *wqt, const float *tparams, const float *ln_gamma,
                                        const float *save, int B, int L, int H, int accumulate_dx,
                                        float *d_dec_in, float *d_kv, float *d_x, float *d_qt_pre,
-                                       float *d_tparams_partial, float *d_ln_partial, void *stream) {
-  MTAM_CHECK_ARG(d_out && dec_in && x && kv && t_query && t_keys && seq_len && wqt && tparams && ln_gamma &&
-                     save && d_dec_in && d_kv && d_x && d_qt_pre && d_tparams_partial && d_ln_partial,
+                                       float *d_tparams_partial, float *d_ln_partial, const float *d_pred,
+                                       const float *head_gamma, const float *head_save, float *d_head_partial,
+                                       void *stream) {
+  MTAM_CHECK_ARG((d_out || d_pred) && dec_in && x && kv && t_query && t_keys && seq_len && wqt && tparams &&
+                     ln_gamma && save && d_dec_in && d_kv && d_x && d_qt_pre && d_tparams_partial && d_ln_partial,
                  "ta_attn_decode_bwd: null argument");
+  MTAM_CHECK_ARG(!d_pred || (head_gamma && head_save && d_head_partial),
+                 "ta_attn_decode_bwd: d_pred needs head_gamma, head_save and d_head_partial");
   int rc = check_attn_common("ta_attn_decode_bwd", B, L, H, ld_kv, k_off, v_off, kv, x);
   if (rc) return rc;
   MTAM_CHECK_ARG(mtam_aligned16(d_kv) && mtam_aligned16(d_x), "ta_attn_decode_bwd: d_kv and d_x must be 16-byte aligned");
   BwdArgs a{d_out, dec_in, x, kv, ld_kv, k_off, v_off, t_query, t_keys, seq_len, wqt, tparams, ln_gamma,
-            save, B, L, H, accumulate_dx, d_dec_in, d_kv, d_x, d_qt_pre, d_tparams_partial, d_ln_partial};
+            save, B, L, H, accumulate_dx, d_dec_in, d_kv, d_x, d_qt_pre, d_tparams_partial, d_ln_partial,
+            d_pred, head_gamma, head_save, d_head_partial};
   hipLaunchKernelGGL(ta_attn_decode_bwd_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("ta_attn_decode_bwd");
   return MTAM_OK;

@@ -137,23 +137,29 @@ def ta_attn_decode_save_floats(L, H):
 
 
 def ta_attn_decode_fwd(dec_in, x, kv, ld_kv, k_off, v_off, t_query, t_keys, seq_len, wqt, bq, tparams,
-                       ln_beta, ln_gamma, B, L, H, dec_out, save):
+                       ln_beta, ln_gamma, B, L, H, dec_out, save, head=None):
+    """head = (beta, gamma, pred_out, head_save): fuse the model's head layer_norm (last block)."""
     lib = _lib.load()
+    hb, hg, po, hs = head if head is not None else (None, None, None, None)
     rc = lib.mtam_ta_attn_decode_fwd(_p(dec_in), _p(x), _p(kv), ld_kv, k_off, v_off, _p(t_query),
                                      _p(t_keys), _pi(seq_len), _p(wqt), _p(bq), _p(tparams), _p(ln_beta),
-                                     _p(ln_gamma), B, L, H, _p(dec_out), _p(save), _stream())
+                                     _p(ln_gamma), B, L, H, _p(dec_out), _p(save), _p(hb), _p(hg), _p(po),
+                                     _p(hs), _stream())
     _lib.check(rc, "mtam_ta_attn_decode_fwd")
 
 
 def ta_attn_decode_bwd(d_out, dec_in, x, kv, ld_kv, k_off, v_off, t_query, t_keys, seq_len, wqt, tparams,
                        ln_gamma, save, B, L, H, accumulate_dx, d_dec_in, d_kv, d_x, d_qt_pre,
-                       d_tparams_partial, d_ln_partial):
+                       d_tparams_partial, d_ln_partial, head=None):
+    """head = (d_pred, head_gamma, head_save, d_head_partial): backward of the fused head layer_norm
+    (d_out may then be None)."""
     lib = _lib.load()
+    dp, hg, hs, dhp = head if head is not None else (None, None, None, None)
     rc = lib.mtam_ta_attn_decode_bwd(_p(d_out), _p(dec_in), _p(x), _p(kv), ld_kv, k_off, v_off,
                                      _p(t_query), _p(t_keys), _pi(seq_len), _p(wqt), _p(tparams),
                                      _p(ln_gamma), _p(save), B, L, H, int(accumulate_dx), _p(d_dec_in),
                                      _p(d_kv), _p(d_x), _p(d_qt_pre), _p(d_tparams_partial),
-                                     _p(d_ln_partial), _stream())
+                                     _p(d_ln_partial), _p(dp), _p(hg), _p(hs), _p(dhp), _stream())
     _lib.check(rc, "mtam_ta_attn_decode_bwd")
 
 
