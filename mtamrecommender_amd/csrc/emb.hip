@@ -6,9 +6,11 @@
 //    Model/base_model.py:302-307).  HBM-bound row copy: a 512-B row is moved by
 //   a half wave as 32 x 16 B, two rows in flight per half wave.
 // Backward (mtam_emb_scatter_add_bwd): the IndexedSlices gradient of the four
-//   lookups, added into dense per-table gradient buffers with wave-level f32
-//   atomics shaped as two 128-B row segments per wave instruction (the
-//   full-rate shape, MI355X_MICROARCH.md "Global float atomics").
+//   lookups, added into dense per-table gradient buffers.  Rows that share an id
+//   inside a 128-slot chunk are summed on chip first (registers, then LDS), so
+//   one f32 atomic row per distinct id leaves the workgroup, each atomic wave
+//   instruction covering two 128-B row segments (the full-rate shape,
+//   MI355X_MICROARCH.md "Global float atomics").
 #include "common.h"
 
 namespace {
