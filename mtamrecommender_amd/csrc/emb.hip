@@ -198,6 +198,11 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
   else                 { d_base = nullptr;    e_base = p.user;   ids = p.user_ids; g = p.g_user; rows = p.user_rows; stride = D; }
 
   // ---- all loads of the block up front, branch-free (clamped addresses, masked afterwards)
+  // (b, t) of slot q = c * CH + i without a per-lane integer division: the chunk's first slot is divided
+  // once on the scalar unit; lanes add i and divide the small remainder (< L + CH) by a multiply-shift
+  // that is exact for L <= 256 (16 waves share 4 SIMDs here: every VALU instruction costs four-fold).
+  const int q0 = c * CH, b0 = q0 / p.L, t0 = q0 - b0 * p.L;
+  const unsigned inv_L = (1u << 20) / (unsigned)p.L + 1u;
   int cand[SPH], id[SPH], sl[SPH], tt[SPH];
 #pragma unroll
   for (int k = 0; k < SPH; ++k) {
@@ -206,8 +211,12 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
     cand[k] = -1;
     tt[k] = -1;                                   // < 0: always live (user)
     if (table <= 1) {
-      const int q = c * CH + i;
-      if (q < R) { cand[k] = q; bb = q / p.L; tt[k] = q - bb * p.L; }
+      const int q = q0 + i;
+      if (q < R) {
+        const int x = t0 + i;
+        const int wraps = p.L <= 256 ? (int)(((unsigned)x * inv_L) >> 20) : x / p.L;
+        cand[k] = q; bb = b0 + wraps; tt[k] = x - wraps * p.L;
+      }
     } else if (table == 2) {
       tt[k] = c % p.L;
       bb = (c / p.L) * CH + i;
