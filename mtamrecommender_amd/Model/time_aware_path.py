@@ -82,7 +82,12 @@ class _Batch(object):
         self.dec = [self.short_n if path.cfg["short_ln"] else self.short] + [f(B, D) for _ in range(NB)]
         self.attn_save = [f(B, ops.ta_attn_decode_save_floats(L, H)) for _ in range(NB)]
         self.pred, self.ln_save = f(B, D), f(B, D + 1)
-        self.logits = f(B, V)
+        # logits rows start on 16-byte boundaries (row stride = V rounded up to 4 floats) so that the
+        # transposed read of d_logits in the item-gradient GEMM takes the vector-load path; `logits` is the
+        # [B, V] view of that storage
+        self.ld_logits = (V + 3) // 4 * 4
+        self.logits_store = f(B, self.ld_logits)
+        self.logits = self.logits_store[:, :V]
         self.lse, self.ce = f(B), f(B)
         self.ce_partial = torch.zeros(ops.softmax_ce_partials(B, V) + 4, dtype=torch.float32, device=dev)
         self.l2_partial = f(ops.emb_gather_partials(B, L))
@@ -249,14 +254,15 @@ class TimeAwarePath(object):
                                        bt.attn_save[i] if training else None, head=head)
         else:
             ops.layer_norm_fwd(bt.short, hl[0], hl[1], 1e-12, B, bt.pred, bt.ln_save if training else None)
-        ops.gemm(bt.pred, T["item"], bt.logits, trans_b=True)
+        ops.gemm(bt.pred, T["item"], bt.logits_store, trans_b=True)
 
     def loss_and_logit_grad(self, bt):
         B, V = bt.B, self.item_rows
         gb = B * self.world_size
         # logits -> lse, ce; then d_logits in place
         # the loss scalar itself is reduced in the step epilogue (clip_and_apply), off the chain
-        ops.softmax_ce_loss(bt.logits, V, bt.feed["target_item_id"], B, V, 1.0 / gb, bt.lse, bt.ce, bt.logits,
+        ops.softmax_ce_loss(bt.logits_store, bt.ld_logits, bt.feed["target_item_id"], B, V, 1.0 / gb, bt.lse, bt.ce,
+                            bt.logits_store,
                             bt.ce_partial, bt.l2_partial, bt.l2_partial.numel(), self.reg, 1.0 / gb, None)
 
     # ---------------------------------------------------------------- backward
@@ -270,15 +276,15 @@ class TimeAwarePath(object):
                                                               ldc=N, M=M, N=N, K=K, split_k=s)
         # dense item gradient dE = G^T pred (every row) and its share of the TF global norm
         if self.tf_compat:
-            ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True, epilogue=ops.EPI_STORE_SQ,
-                     aux_out=part[self.nb_dense:])
+            ops.gemm(bt.logits_store, bt.pred, self.g_tab["item"], trans_a=True, epilogue=ops.EPI_STORE_SQ,
+                     aux_out=part[self.nb_dense:], M=self.item_rows)
         else:
-            ops.gemm(bt.logits, bt.pred, self.g_tab["item"], trans_a=True)
+            ops.gemm(bt.logits_store, bt.pred, self.g_tab["item"], trans_a=True, M=self.item_rows)
         # d_pred = G E -> head LN -> decoder blocks (last to first)
         # split-K over the catalog: ~64 slices at ml-1m sizes; for large catalogs enough slices (<= 1024) that
         # 2,000+ workgroups stream the table (64 slices left one workgroup per CU: 43 TFLOP/s at V = 1 M)
         split_v = max(1, min(64, (self.item_rows + 127) // 128), min(1024, self.item_rows // 2048))
-        ops.gemm(bt.logits, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v)
+        ops.gemm(bt.logits_store, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v, K=self.item_rows)
         keys = bt.hs if cfg["keys"] == "gru" else bt.x
         d_keys = bt.d_hs if cfg["keys"] == "gru" else bt.d_x      # gradient of user_history
         problems, jobs = [], []
@@ -380,7 +386,7 @@ class TimeAwarePath(object):
 
     def eval_kernels(self, bt, k=50):
         self.forward(bt, training=False)
-        ops.topk(bt.logits, self.item_rows, bt.B, self.item_rows, k, bt.topk_idx)
+        ops.topk(bt.logits_store, bt.ld_logits, bt.B, self.item_rows, k, bt.topk_idx)
 
     # ------------------------------------------------------- weights in / out
     def dense_tf(self):

@@ -23,8 +23,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 32;
-constexpr int LDK = 65;  // LDS row stride when the source is k-contiguous (transposing write)
-constexpr int LDM = 68;  // LDS row stride when the source is m/n-contiguous (row write, 16-B aligned)
+// LDS row strides for a tile edge of E rows/columns: E + 1 when the source is k-contiguous (transposing
+// write), E + 4 when it is m/n-contiguous (row write, 16-B aligned)
 
 struct GemmArgs {
   const float *A, *B;
@@ -43,12 +43,12 @@ struct GemmArgs {
 // Source laid out src[r][k] (k contiguous): tile of 64 rows x 32 k.
 // FAST: the whole tile is in range and 16-B aligned (decided per block / per k-tile, wave-uniform),
 // so the loads are straight-line dwordx4 with nothing between them for the compiler to wait on.
-template <bool FAST>
+template <bool FAST, int E>
 __device__ __forceinline__ void load_kcontig(const float *__restrict__ src, int ld, int rows, int r0,
-                                             int k0, int kend, float4 (&reg)[2]) {
+                                             int k0, int kend, float4 (&reg)[E / 32]) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < E / 32; ++i) {
     const int idx = t + 256 * i;
     const int r = r0 + (idx >> 3);
     const int k = k0 + 4 * (idx & 7);
@@ -67,30 +67,32 @@ __device__ __forceinline__ void load_kcontig(const float *__restrict__ src, int 
     }
   }
 }
-__device__ __forceinline__ void store_kcontig(float *__restrict__ S, const float4 (&reg)[2]) {
+template <int E>
+__device__ __forceinline__ void store_kcontig(float *__restrict__ S, const float4 (&reg)[E / 32]) {
+  constexpr int LD = E + 1;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < E / 32; ++i) {
     const int idx = t + 256 * i;
     const int r = idx >> 3;
     const int k = 4 * (idx & 7);
-    S[(k + 0) * LDK + r] = reg[i].x;
-    S[(k + 1) * LDK + r] = reg[i].y;
-    S[(k + 2) * LDK + r] = reg[i].z;
-    S[(k + 3) * LDK + r] = reg[i].w;
+    S[(k + 0) * LD + r] = reg[i].x;
+    S[(k + 1) * LD + r] = reg[i].y;
+    S[(k + 2) * LD + r] = reg[i].z;
+    S[(k + 3) * LD + r] = reg[i].w;
   }
 }
 
-// Source laid out src[k][c] (c contiguous): tile of 32 k x 64 columns.
-template <bool FAST>
+// Source laid out src[k][c] (c contiguous): tile of 32 k x E columns.
+template <bool FAST, int E>
 __device__ __forceinline__ void load_ccontig(const float *__restrict__ src, int ld, int cols, int c0,
-                                             int k0, int kend, float4 (&reg)[2]) {
+                                             int k0, int kend, float4 (&reg)[E / 32]) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < E / 32; ++i) {
     const int idx = t + 256 * i;
-    const int k = k0 + (idx >> 4);
-    const int c = c0 + 4 * (idx & 15);
+    const int k = k0 + idx / (E / 4);
+    const int c = c0 + 4 * (idx % (E / 4));
     if (FAST) {
       reg[i] = *reinterpret_cast<const float4 *>(src + (size_t)k * ld + c);
     } else {
@@ -106,18 +108,21 @@ __device__ __forceinline__ void load_ccontig(const float *__restrict__ src, int 
     }
   }
 }
-__device__ __forceinline__ void store_ccontig(float *__restrict__ S, const float4 (&reg)[2]) {
+template <int E>
+__device__ __forceinline__ void store_ccontig(float *__restrict__ S, const float4 (&reg)[E / 32]) {
+  constexpr int LD = E + 4;
   const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < E / 32; ++i) {
     const int idx = t + 256 * i;
-    const int k = idx >> 4;
-    const int c = 4 * (idx & 15);
-    *reinterpret_cast<float4 *>(&S[k * LDM + c]) = reg[i];
+    const int k = idx / (E / 4);
+    const int c = 4 * (idx % (E / 4));
+    *reinterpret_cast<float4 *>(&S[k * LD + c]) = reg[i];
   }
 }
 
-constexpr int TILE_FLOATS = BK * LDM;   // one operand tile in LDS
+template <int E> constexpr int tile_floats() { return BK * (E + 4); }   // one operand tile in LDS
+constexpr int TILE_FLOATS = tile_floats<64>();
 
 // One wave's 32x32 accumulator -> C with the fused epilogue.
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -125,9 +130,9 @@ constexpr int TILE_FLOATS = BK * LDM;   // one operand tile in LDS
 // as load-compute-store per row, possible aliasing made the compiler wait out a full memory round
 // trip per row (16 rows: 12,000 cycles for RELU_ADD, 36,000 for ACCUM2_MASK, tools/gemm_lab.hip).
 template <int EPI>
-__device__ __forceinline__ void store_acc(const GemmArgs &p, const f32x16 &acc, int row0, int gn, int lane) {
-  float sq = 0.f;
-  if (EPI != MTAM_EPI_STORE_SQ && gn >= p.N) return;
+__device__ __forceinline__ float store_acc(const GemmArgs &p, const f32x16 &acc, int row0, int gn, int lane) {
+  float sq = 0.f;          // STORE_SQ: this lane's sum of acc^2 over its in-range elements
+  if (gn >= p.N) return sq;
   constexpr bool READ_C = EPI == MTAM_EPI_ACCUM || EPI == MTAM_EPI_ACCUM_MASK || EPI == MTAM_EPI_ACCUM2_MASK;
   constexpr bool READ_AUX = EPI == MTAM_EPI_RELU_ADD || EPI == MTAM_EPI_ACCUM_MASK || EPI == MTAM_EPI_ACCUM2_MASK;
   constexpr bool READ_BIAS2 = EPI == MTAM_EPI_ACCUM2_MASK;
@@ -176,18 +181,21 @@ __device__ __forceinline__ void store_acc(const GemmArgs &p, const f32x16 &acc, 
       atomicAdd(c, v);
     }
   }
-  if (EPI == MTAM_EPI_STORE_SQ) {
-    sq = wave_sum(sq);
-    if ((lane & 63) == 0) p.aux_out[4 * (size_t)blockIdx.x + (threadIdx.x >> 6)] = sq;
-  }
+  return sq;
 }
 
 // One 64x64 output tile over one K slice.  LDS: As[2][TILE_FLOATS], Bs[2][TILE_FLOATS]
 // (double buffered: the tile for step kt+1 is written while step kt is multiplied; one barrier per step).
-template <bool TA, bool TB, int EPI>
+// MW = 32-row blocks per wave: 1 -> the 64x64 workgroup tile; 2 -> a 128x64 tile whose waves own 64x32
+// (two accumulators: twice the MFMA work per staged byte and two independent chains that issue back
+// to back) for problems with thousands of tiles, e.g. the [B, V] scoring products at V >= 1 M.
+template <int MW, bool TA, bool TB, int EPI>
 __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *Bs, int tile, int kslice) {
-  constexpr int LDA_S = TA ? LDM : LDK;
-  constexpr int LDB_S = TB ? LDK : LDM;
+  constexpr int EA = 64 * MW;                   // A-tile rows
+  constexpr int LDA_S = TA ? EA + 4 : EA + 1;
+  constexpr int LDB_S = TB ? BN + 1 : BN + 4;
+  constexpr int A_FLOATS = tile_floats<EA>(), B_FLOATS = tile_floats<BN>();
+  constexpr int BM = EA;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -199,50 +207,54 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
   const bool fullA = p.vecA && (m0 + BM <= p.M);
   const bool fullB = p.vecB && (n0 + BN <= p.N);
 
-  f32x16 acc;
+  f32x16 acc, acc2;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 16; ++i) acc[i] = acc2[i] = 0.f;
 
-  float4 ra[2], rb[2];
+  float4 ra[EA / 32], rb[BN / 32];
   auto load_tiles = [&](int k0) {
     const bool fullK = (k0 + BK <= kend);
     if (fullA && fullK) {
-      if (TA) load_ccontig<true>(p.A, p.lda, p.M, m0, k0, kend, ra);
-      else    load_kcontig<true>(p.A, p.lda, p.M, m0, k0, kend, ra);
+      if (TA) load_ccontig<true, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
+      else    load_kcontig<true, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
     } else {
-      if (TA) load_ccontig<false>(p.A, p.lda, p.M, m0, k0, kend, ra);
-      else    load_kcontig<false>(p.A, p.lda, p.M, m0, k0, kend, ra);
+      if (TA) load_ccontig<false, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
+      else    load_kcontig<false, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
     }
     if (fullB && fullK) {
-      if (TB) load_kcontig<true>(p.B, p.ldb, p.N, n0, k0, kend, rb);
-      else    load_ccontig<true>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+      if (TB) load_kcontig<true, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+      else    load_ccontig<true, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
     } else {
-      if (TB) load_kcontig<false>(p.B, p.ldb, p.N, n0, k0, kend, rb);
-      else    load_ccontig<false>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+      if (TB) load_kcontig<false, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+      else    load_ccontig<false, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
     }
   };
   auto store_tiles = [&](int buf) {
-    float *a = As + buf * TILE_FLOATS, *b = Bs + buf * TILE_FLOATS;
-    if (TA) store_ccontig(a, ra); else store_kcontig(a, ra);
-    if (TB) store_kcontig(b, rb); else store_ccontig(b, rb);
+    float *a = As + buf * A_FLOATS, *b = Bs + buf * B_FLOATS;
+    if (TA) store_ccontig<EA>(a, ra); else store_kcontig<EA>(a, ra);
+    if (TB) store_kcontig<BN>(b, rb); else store_ccontig<BN>(b, rb);
   };
 
   if (kbeg < kend) {
     const int nk = (kend - kbeg + BK - 1) / BK;
-    const int a_off = (lane >> 5) * LDA_S + wm * 32 + (lane & 31);
+    const int a_off = (lane >> 5) * LDA_S + wm * (32 * MW) + (lane & 31);
     const int b_off = (lane >> 5) * LDB_S + wn * 32 + (lane & 31);
     auto multiply = [&](int kt) {
-      const float *a_s = As + (kt & 1) * TILE_FLOATS + a_off;
-      const float *b_s = Bs + (kt & 1) * TILE_FLOATS + b_off;
-      float fa[BK / 2], fb[BK / 2];
+      const float *a_s = As + (kt & 1) * A_FLOATS + a_off;
+      const float *b_s = Bs + (kt & 1) * B_FLOATS + b_off;
+      float fa[BK / 2], fa2[BK / 2], fb[BK / 2];
 #pragma unroll
       for (int q = 0; q < BK / 2; ++q) {
         fa[q] = a_s[2 * q * LDA_S];
+        if (MW == 2) fa2[q] = a_s[2 * q * LDA_S + 32];
         fb[q] = b_s[2 * q * LDB_S];
       }
       GEMM_STAMP(1);
 #pragma unroll
-      for (int q = 0; q < BK / 2; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
+      for (int q = 0; q < BK / 2; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
+        if (MW == 2) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa2[q], fb[q], acc2, 0, 0, 0);
+      }
       GEMM_STAMP(2);
     };
     GEMM_STAMP_DECL;
@@ -252,12 +264,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
       // and the global loads of the tile after it are placed INTO those gaps instead of after the
       // chain, where a lone wave per SIMD ran them un-overlapped (1,100 of 2,900 cycles per k-tile).
       auto load_fast = [&](int k0) {
-        if (TA) load_ccontig<true>(p.A, p.lda, p.M, m0, k0, kend, ra);
-        else    load_kcontig<true>(p.A, p.lda, p.M, m0, k0, kend, ra);
-        if (TB) load_kcontig<true>(p.B, p.ldb, p.N, n0, k0, kend, rb);
-        else    load_ccontig<true>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+        if (TA) load_ccontig<true, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
+        else    load_kcontig<true, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
+        if (TB) load_kcontig<true, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+        else    load_ccontig<true, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
       };
-      constexpr int N_DSW = (TA ? 2 : 4) + (TB ? 4 : 2);     // ds_write2_b32 pairs / ds_write_b128 per k-tile
+      // ds_write2_b32 pairs / ds_write_b128 per k-tile
+      constexpr int N_DSW = (TA ? 2 : 4) * MW + (TB ? 4 : 2);
       load_fast(kbeg);
       store_tiles(0);
       if (nk > 1) load_fast(kbeg + BK);
@@ -270,9 +283,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
         load_fast(kbeg + (kt + 2) * BK);
 #pragma unroll
         for (int i = 0; i < BK / 2; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x008, MW, 0);                      // one MFMA per chain
           if (i >= 2 && i < 2 + N_DSW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-          if (i >= 10 && i < 14) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+          if (i >= 10 && i < 12 + 2 * MW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
         }
         GEMM_STAMP(3);
         __syncthreads();
@@ -302,12 +315,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
     }
   }
 
-  store_acc<EPI>(p, acc, m0 + wm * 32, n0 + wn * 32 + (lane & 31), lane);
+  float sq = store_acc<EPI>(p, acc, m0 + wm * (32 * MW), n0 + wn * 32 + (lane & 31), lane);
+  if (MW == 2) sq += store_acc<EPI>(p, acc2, m0 + wm * 64 + 32, n0 + wn * 32 + (lane & 31), lane);
+  if (EPI == MTAM_EPI_STORE_SQ) {
+    sq = wave_sum(sq);
+    if (lane == 0) p.aux_out[4 * (size_t)blockIdx.x + wave] = sq;
+  }
 }
 
-template <bool TA, bool TB, int EPI>
+template <int MW, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float As[2 * TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float As[2 * tile_floats<64 * MW>()];
   __shared__ __attribute__((aligned(16))) float Bs[2 * TILE_FLOATS];
   // 1-D tile index (grid.y is capped at 65535; V/64 is not), split-K slice on grid.y
   if (p.heads > 0) {                       // batched: grid.y is the batch index, no split-K
@@ -316,10 +334,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     q.A += z0 * p.sA0 + z1 * p.sA1;
     q.B += z0 * p.sB0 + z1 * p.sB1;
     q.C += z0 * p.sC0 + z1 * p.sC1;
-    gemm_tile<TA, TB, EPI>(q, As, Bs, blockIdx.x, 0);
+    gemm_tile<MW, TA, TB, EPI>(q, As, Bs, blockIdx.x, 0);
     return;
   }
-  gemm_tile<TA, TB, EPI>(p, As, Bs, blockIdx.x, blockIdx.y);
+  gemm_tile<MW, TA, TB, EPI>(p, As, Bs, blockIdx.x, blockIdx.y);
 }
 
 // Grouped weight-gradient form: up to MTAM_MAX_GROUP independent C += A^T B problems
@@ -387,7 +405,7 @@ __global__ __launch_bounds__(256) void weight_grads_kernel(WeightGradArgs wa) {
   const GemmArgs &p = ga.g[g];
   const int local = blockIdx.x - ga.first[g];
   const int tiles = p.tiles_n * ((p.M + BM - 1) / BM);
-  gemm_tile<true, false, MTAM_EPI_ATOMIC>(p, As, Bs, local % tiles, local / tiles);
+  gemm_tile<1, true, false, MTAM_EPI_ATOMIC>(p, As, Bs, local % tiles, local / tiles);
 }
 
 __global__ __launch_bounds__(256) void gemm_tn_atomic_grouped_kernel(GroupArgs ga) {
@@ -398,27 +416,47 @@ __global__ __launch_bounds__(256) void gemm_tn_atomic_grouped_kernel(GroupArgs g
   const GemmArgs &p = ga.g[g];
   const int local = blockIdx.x - ga.first[g];
   const int tiles = p.tiles_n * ((p.M + BM - 1) / BM);
-  gemm_tile<true, false, MTAM_EPI_ATOMIC>(p, As, Bs, local % tiles, local / tiles);
+  gemm_tile<1, true, false, MTAM_EPI_ATOMIC>(p, As, Bs, local % tiles, local / tiles);
 }
 
-template <bool TA, bool TB>
+template <int MW, bool TA, bool TB>
 void launch_epi(int epi, dim3 grid, hipStream_t s, const GemmArgs &a) {
   switch (epi) {
-    case MTAM_EPI_STORE: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_STORE>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_BIAS: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_BIAS>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_BIAS_RELU>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_RELU_ADD: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_RELU_ADD>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ACCUM>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_ACCUM_MASK: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ACCUM_MASK>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_ACCUM2_MASK: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ACCUM2_MASK>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_STORE_SQ: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_STORE_SQ>), grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, MTAM_EPI_ATOMIC>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_STORE: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_STORE>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_BIAS: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_BIAS>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_BIAS_RELU>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_RELU_ADD: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_RELU_ADD>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ACCUM>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_ACCUM_MASK: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ACCUM_MASK>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_ACCUM2_MASK: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ACCUM2_MASK>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_STORE_SQ: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_STORE_SQ>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ATOMIC>), grid, dim3(256), 0, s, a); break;
   }
+}
+template <int MW>
+void launch_trans(int trans_a, int trans_b, int epi, dim3 grid, hipStream_t s, const GemmArgs &a) {
+  if (trans_a) {
+    if (trans_b) launch_epi<MW, true, true>(epi, grid, s, a);
+    else         launch_epi<MW, true, false>(epi, grid, s, a);
+  } else {
+    if (trans_b) launch_epi<MW, false, true>(epi, grid, s, a);
+    else         launch_epi<MW, false, false>(epi, grid, s, a);
+  }
+}
+
+// 128x64 tiles once a problem has this many of them (and at least 128 rows): enough workgroups to fill
+// the chip several times over, so the larger tile's higher MFMA work per staged byte wins.
+constexpr long TALL_TILE_MIN_UNITS = 2048;
+bool use_tall_tile(int M, int N, long batches_or_slices) {
+  return M >= 128 && (long)((M + 127) / 128) * ((N + BN - 1) / BN) * batches_or_slices >= TALL_TILE_MIN_UNITS;
 }
 
 }  // namespace
 
-extern "C" int mtam_gemm_sq_partials(int M, int N) { return 4 * ((M + BM - 1) / BM) * ((N + BN - 1) / BN); }
+extern "C" int mtam_gemm_sq_partials(int M, int N) {
+  const int bm = use_tall_tile(M, N, 1) ? 128 : BM;
+  return 4 * ((M + bm - 1) / bm) * ((N + BN - 1) / BN);
+}
 
 extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                              const float *B, int ldb, float *C, int ldc, int epilogue,
@@ -440,7 +478,8 @@ extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, cons
   int k_chunk = (K + split_k - 1) / split_k;
   k_chunk = ((k_chunk + BK - 1) / BK) * BK;
   split_k = (K + k_chunk - 1) / k_chunk;
-  const long gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+  const bool tall = use_tall_tile(M, N, split_k);
+  const long gx = (N + BN - 1) / BN, gy = tall ? (M + 127) / 128 : (M + BM - 1) / BM;
   MTAM_CHECK_ARG(gx * gy <= 0x7fffffffL && split_k <= 65535, "gemm: grid too large");
 
   GemmArgs a;
@@ -454,13 +493,8 @@ extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, cons
   a.sA0 = a.sA1 = a.sB0 = a.sB1 = a.sC0 = a.sC1 = 0;
   dim3 grid((unsigned)(gx * gy), (unsigned)split_k, 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (trans_a) {
-    if (trans_b) launch_epi<true, true>(epilogue, grid, s, a);
-    else         launch_epi<true, false>(epilogue, grid, s, a);
-  } else {
-    if (trans_b) launch_epi<false, true>(epilogue, grid, s, a);
-    else         launch_epi<false, false>(epilogue, grid, s, a);
-  }
+  if (tall) launch_trans<2>(trans_a, trans_b, epilogue, grid, s, a);
+  else      launch_trans<1>(trans_a, trans_b, epilogue, grid, s, a);
   MTAM_CHECK_LAUNCH("gemm");
   return MTAM_OK;
 }
@@ -488,13 +522,7 @@ extern "C" int mtam_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int
   a.sA0 = sA0; a.sA1 = sA1; a.sB0 = sB0; a.sB1 = sB1; a.sC0 = sC0; a.sC1 = sC1;
   dim3 grid((unsigned)(gx * gy), (unsigned)(batch0 * batch1), 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (trans_a) {
-    if (trans_b) launch_epi<true, true>(epilogue, grid, s, a);
-    else         launch_epi<true, false>(epilogue, grid, s, a);
-  } else {
-    if (trans_b) launch_epi<false, true>(epilogue, grid, s, a);
-    else         launch_epi<false, false>(epilogue, grid, s, a);
-  }
+  launch_trans<1>(trans_a, trans_b, epilogue, grid, s, a);
   MTAM_CHECK_LAUNCH("gemm_batched");
   return MTAM_OK;
 }

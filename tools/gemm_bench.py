@@ -53,6 +53,9 @@ if __name__ == "__main__":
     run("dE TN", 3709, 128, 128, ta=True)
     run("dpred atomic", 128, 128, 3709, epi=6, split=29)
     run("dWx TN atomic", 128, 384, 6400, ta=True, epi=6, split=16)
+    run("logits V=1M NT", 128, 1000003, 128, tb=True)
+    run("dE V=1M TN", 1000003, 128, 128, ta=True)
+    run("dpred V=1M atomic", 128, 128, 1000003, epi=6, split=488)
     run("big square", 4096, 4096, 4096)
     run("big square NT", 4096, 4096, 4096, tb=True)
     run("tall K=32", 6400, 128, 32)
