@@ -536,7 +536,8 @@ def test_softmax_ce_loss_fused(ops, B, V):
 
 
 # ------------------------------------------------------------------ top-K
-@pytest.mark.parametrize("rows,V,k", [(4, 10, 50), (7, 3709, 50), (3, 70000, 50), (5, 300, 1), (2, 64, 64)])
+@pytest.mark.parametrize("rows,V,k", [(4, 10, 50), (7, 3709, 50), (3, 70000, 50), (5, 300, 1), (2, 64, 64),
+                                      (4, 1000003, 50)])
 def test_topk_bit_exact(ops, rows, V, k):
     import oracle.mtam_oracle as O
     rng = np.random.default_rng(rows + V + k)
@@ -547,6 +548,8 @@ def test_topk_bit_exact(ops, rows, V, k):
     if rows > 2:
         scores[2, ::3] = -0.0
         scores[2, 1::3] = 0.0
+    if rows > 3:
+        scores[3] = 0.75                                  # a constant row: more ties than the tie list holds
     idx = torch.zeros((rows, k), dtype=torch.int32, device="cuda")
     val = torch.zeros((rows, k), device="cuda")
     ops.topk(dev(scores), V, rows, V, k, idx, val)
