@@ -48,7 +48,8 @@ def time_kernel(fn, torch, reps=50, replays=20):
         fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    kw = {"capture_error_mode": "thread_local"} if torch.distributed.is_initialized() else {}
+    with torch.cuda.graph(g, **kw):
         for _ in range(reps):
             fn()
     g.replay()

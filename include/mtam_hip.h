@@ -82,6 +82,15 @@ int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
                   const float *aux_in, float *aux_out, int ld_aux,
                   int split_k, void *stream);
 
+/* C = op(A) op(B) + op(A2) op(B2) (+ epilogue): the same kernel with a second (A2, B2, K2) source whose
+ * k-tiles are accumulated into the same output tile after the first source's -- two matmul gradients that
+ * meet in one tensor (d x = d(xproj) Wx^T + d(kv) Wkv^T) in one launch.  Same transposes for both sources. */
+int mtam_gemm_f32_dual(int trans_a, int trans_b, int M, int N, int K,
+                       const float *A, int lda, const float *B, int ldb,
+                       int K2, const float *A2, int lda2, const float *B2, int ldb2,
+                       float *C, int ldc, int epilogue, const float *bias,
+                       const float *aux_in, float *aux_out, int ld_aux, void *stream);
+
 /* Batched GEMM: batch0 x batch1 independent problems of one shape in one launch; problem (z0, z1)
  * uses A + z0*sA0 + z1*sA1 (element offsets; same for B and C).  The L x L products of the
  * self-attention encoder: Q_h K_h^T, (q Wt) k^T, W V and their gradients

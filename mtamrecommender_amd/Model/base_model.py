@@ -206,6 +206,10 @@ class base_model(object):
                 return
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                # a process group's watchdog thread may query events while this thread captures: keep the
+                # capture's error checking local to this thread
+                graph_kw.setdefault("capture_error_mode", "thread_local")
             with torch.cuda.graph(g, **graph_kw):        # records the launches, executes nothing
                 fn(bt)
             self._graphs[key] = g

@@ -307,8 +307,10 @@ class TimeAwarePath(object):
                 jobs += [(bt.d_qt[i], B, D, 2 * D, gseg("blk%d/bq" % i)),
                          (bt.d_tp_partial[i], B, 5 * L, 5 * L, gseg("blk%d/tparams" % i).view(-1)),
                          (bt.d_ln_partial[i], B, 2 * D, 2 * D, gseg("blk%d/ln" % i).view(-1))]
-            # d(user_history) += d_kv . Wkv^T
-            ops.gemm(bt.d_kv, self.seg("kv/w"), d_keys, trans_b=True, epilogue=ops.EPI_ACCUM)
+            # d(user_history) += d_kv . Wkv^T: needed before the GRU's backward when the keys are its outputs;
+            # with x as keys it rides along in the d_x GEMM below (second source)
+            if cfg["keys"] == "gru":
+                ops.gemm(bt.d_kv, self.seg("kv/w"), d_keys, trans_b=True, epilogue=ops.EPI_ACCUM)
             d_short = bt.d_dec[0]
         else:
             ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_short, gseg("head/ln"))
@@ -333,8 +335,12 @@ class TimeAwarePath(object):
         # (members without a decoder leave it untouched: cleared here)
         if not cfg["attention"]:
             bt.d_x.zero_()
-        ops.gemm(bt.d_xproj, self.seg("gru/wx"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM2_MASK,
-                 bias=bt.d_xt, aux_in=bt.zr, aux_out=bt.d_z)
+        if cfg["attention"] and cfg["keys"] == "x":
+            ops.gemm_dual(bt.d_xproj, self.seg("gru/wx"), bt.d_kv, self.seg("kv/w"), bt.d_x, trans_b=True,
+                          epilogue=ops.EPI_ACCUM2_MASK, bias=bt.d_xt, aux_in=bt.zr, aux_out=bt.d_z)
+        else:
+            ops.gemm(bt.d_xproj, self.seg("gru/wx"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM2_MASK,
+                     bias=bt.d_xt, aux_in=bt.zr, aux_out=bt.d_z)
         ops.gemm(bt.d_z, self.seg("dense4emb/w"), bt.d_ic, trans_b=True)
         problems.append(prob(bt.ic, 2 * D, bt.d_z, D, "dense4emb/w", 2 * D, D, R, sr))
         # every weight gradient and every bias-like gradient in ONE launch (more when a group overflows)

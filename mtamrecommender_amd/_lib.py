@@ -19,6 +19,8 @@ SIGNATURES = {
     "mtam_version": (c_int, []),
     "mtam_arch": (ctypes.c_char_p, []),
     "mtam_gemm_sq_partials": (c_int, [c_int, c_int]),
+    "mtam_gemm_f32_dual": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int, P, c_int,
+                                   P, c_int, c_int, P, P, P, c_int, P]),
     "mtam_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, c_int,
                               P, P, P, c_int, c_int, P]),
     "mtam_gemm_f32_batched": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, ctypes.c_long, ctypes.c_long,

@@ -38,6 +38,9 @@ struct GemmArgs {
   // batched form: grid.y = batch index z -> (z / heads, z % heads), element offsets per operand
   int heads;
   long sA0, sA1, sB0, sB1, sC0, sC1;
+  // optional second source accumulated into the same output tile (same transposes; no split-K)
+  const float *A2, *B2;
+  int K2, lda2, ldb2, vec2;
 };
 
 // Source laid out src[r][k] (k contiguous): tile of 64 rows x 32 k.
@@ -201,11 +204,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
   const int wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-  const int kbeg = kslice * p.k_chunk;
-  const int kend = min(p.K, kbeg + p.k_chunk);
+  // the current source of the product: (A, B, K); a second source (A2, B2, K2) is accumulated into the same
+  // tile afterwards (C = A B + A2 B2: two matmul gradients that meet in one tensor, one launch)
+  const float *Asrc = p.A, *Bsrc = p.B;
+  int lda = p.lda, ldb = p.ldb;
+  int kbeg = kslice * p.k_chunk;
+  int kend = min(p.K, kbeg + p.k_chunk);
   // wave-uniform: whole tile rows/columns in range and vector loads legal
-  const bool fullA = p.vecA && (m0 + BM <= p.M);
-  const bool fullB = p.vecB && (n0 + BN <= p.N);
+  bool fullA = p.vecA && (m0 + BM <= p.M);
+  bool fullB = p.vecB && (n0 + BN <= p.N);
 
   f32x16 acc, acc2;
 #pragma unroll
@@ -215,18 +222,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
   auto load_tiles = [&](int k0) {
     const bool fullK = (k0 + BK <= kend);
     if (fullA && fullK) {
-      if (TA) load_ccontig<true, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
-      else    load_kcontig<true, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
+      if (TA) load_ccontig<true, EA>(Asrc, lda, p.M, m0, k0, kend, ra);
+      else    load_kcontig<true, EA>(Asrc, lda, p.M, m0, k0, kend, ra);
     } else {
-      if (TA) load_ccontig<false, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
-      else    load_kcontig<false, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
+      if (TA) load_ccontig<false, EA>(Asrc, lda, p.M, m0, k0, kend, ra);
+      else    load_kcontig<false, EA>(Asrc, lda, p.M, m0, k0, kend, ra);
     }
     if (fullB && fullK) {
-      if (TB) load_kcontig<true, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
-      else    load_ccontig<true, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+      if (TB) load_kcontig<true, BN>(Bsrc, ldb, p.N, n0, k0, kend, rb);
+      else    load_ccontig<true, BN>(Bsrc, ldb, p.N, n0, k0, kend, rb);
     } else {
-      if (TB) load_kcontig<false, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
-      else    load_ccontig<false, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+      if (TB) load_kcontig<false, BN>(Bsrc, ldb, p.N, n0, k0, kend, rb);
+      else    load_ccontig<false, BN>(Bsrc, ldb, p.N, n0, k0, kend, rb);
     }
   };
   auto store_tiles = [&](int buf) {
@@ -235,6 +242,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
     if (TB) store_kcontig<BN>(b, rb); else store_ccontig<BN>(b, rb);
   };
 
+  for (int src = 0; src < (p.A2 ? 2 : 1); ++src) {
+  if (src == 1) {
+    Asrc = p.A2; Bsrc = p.B2; lda = p.lda2; ldb = p.ldb2;
+    kbeg = 0; kend = p.K2;
+    fullA = p.vec2 && (m0 + BM <= p.M);
+    fullB = p.vec2 && (n0 + BN <= p.N);
+  }
   if (kbeg < kend) {
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int a_off = (lane >> 5) * LDA_S + wm * (32 * MW) + (lane & 31);
@@ -264,10 +278,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
       // and the global loads of the tile after it are placed INTO those gaps instead of after the
       // chain, where a lone wave per SIMD ran them un-overlapped (1,100 of 2,900 cycles per k-tile).
       auto load_fast = [&](int k0) {
-        if (TA) load_ccontig<true, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
-        else    load_kcontig<true, EA>(p.A, p.lda, p.M, m0, k0, kend, ra);
-        if (TB) load_kcontig<true, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
-        else    load_ccontig<true, BN>(p.B, p.ldb, p.N, n0, k0, kend, rb);
+        if (TA) load_ccontig<true, EA>(Asrc, lda, p.M, m0, k0, kend, ra);
+        else    load_kcontig<true, EA>(Asrc, lda, p.M, m0, k0, kend, ra);
+        if (TB) load_kcontig<true, BN>(Bsrc, ldb, p.N, n0, k0, kend, rb);
+        else    load_ccontig<true, BN>(Bsrc, ldb, p.N, n0, k0, kend, rb);
       };
       // ds_write2_b32 pairs / ds_write_b128 per k-tile
       constexpr int N_DSW = (TA ? 2 : 4) * MW + (TB ? 4 : 2);
@@ -314,6 +328,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
       }
     }
   }
+
+  }   // sources
 
   float sq = store_acc<EPI>(p, acc, m0 + wm * (32 * MW), n0 + wn * 32 + (lane & 31), lane);
   if (MW == 2) sq += store_acc<EPI>(p, acc2, m0 + wm * 64 + 32, n0 + wn * 32 + (lane & 31), lane);
@@ -458,10 +474,10 @@ extern "C" int mtam_gemm_sq_partials(int M, int N) {
   return 4 * ((M + bm - 1) / bm) * ((N + BN - 1) / BN);
 }
 
-extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
-                             const float *B, int ldb, float *C, int ldc, int epilogue,
-                             const float *bias, const float *aux_in, float *aux_out, int ld_aux,
-                             int split_k, void *stream) {
+static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda, const float *B,
+                     int ldb, int K2, const float *A2, int lda2, const float *B2, int ldb2, float *C, int ldc,
+                     int epilogue, const float *bias, const float *aux_in, float *aux_out, int ld_aux,
+                     int split_k, void *stream) {
   MTAM_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive (got %d %d %d)", M, N, K);
   MTAM_CHECK_ARG(A && B && C, "gemm: null operand");
   MTAM_CHECK_ARG(epilogue >= MTAM_EPI_STORE && epilogue <= MTAM_EPI_STORE_SQ, "gemm: bad epilogue %d", epilogue);
@@ -491,12 +507,36 @@ extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, cons
   a.tiles_n = (int)gx;
   a.heads = 0;
   a.sA0 = a.sA1 = a.sB0 = a.sB1 = a.sC0 = a.sC1 = 0;
+  a.A2 = a.B2 = nullptr; a.K2 = a.lda2 = a.ldb2 = a.vec2 = 0;
+  if (A2) {
+    MTAM_CHECK_ARG(B2 && K2 > 0 && split_k == 1, "gemm_dual: second source needs B2, K2 > 0 and no split-K");
+    MTAM_CHECK_ARG(lda2 >= (trans_a ? M : K2) && ldb2 >= (trans_b ? K2 : N), "gemm_dual: bad leading dimension");
+    a.A2 = A2; a.B2 = B2; a.K2 = K2; a.lda2 = lda2; a.ldb2 = ldb2;
+    a.vec2 = (lda2 % 4 == 0) && (ldb2 % 4 == 0) && mtam_aligned16(A2) && mtam_aligned16(B2);
+  }
   dim3 grid((unsigned)(gx * gy), (unsigned)split_k, 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (tall) launch_trans<2>(trans_a, trans_b, epilogue, grid, s, a);
   else      launch_trans<1>(trans_a, trans_b, epilogue, grid, s, a);
   MTAM_CHECK_LAUNCH("gemm");
   return MTAM_OK;
+}
+
+extern "C" int mtam_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                             const float *B, int ldb, float *C, int ldc, int epilogue,
+                             const float *bias, const float *aux_in, float *aux_out, int ld_aux,
+                             int split_k, void *stream) {
+  return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, 0, nullptr, 0, nullptr, 0, C, ldc, epilogue, bias,
+                   aux_in, aux_out, ld_aux, split_k, stream);
+}
+
+extern "C" int mtam_gemm_f32_dual(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                                  const float *B, int ldb, int K2, const float *A2, int lda2, const float *B2,
+                                  int ldb2, float *C, int ldc, int epilogue, const float *bias,
+                                  const float *aux_in, float *aux_out, int ld_aux, void *stream) {
+  MTAM_CHECK_ARG(A2 && B2, "gemm_dual: null second source");
+  return gemm_impl(trans_a, trans_b, M, N, K, A, lda, B, ldb, K2, A2, lda2, B2, ldb2, C, ldc, epilogue, bias,
+                   aux_in, aux_out, ld_aux, 1, stream);
 }
 
 
@@ -520,6 +560,7 @@ extern "C" int mtam_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int
   a.tiles_n = (int)gx;
   a.heads = batch1;
   a.sA0 = sA0; a.sA1 = sA1; a.sB0 = sB0; a.sB1 = sB1; a.sC0 = sC0; a.sC1 = sC1;
+  a.A2 = a.B2 = nullptr; a.K2 = a.lda2 = a.ldb2 = a.vec2 = 0;
   dim3 grid((unsigned)(gx * gy), (unsigned)(batch0 * batch1), 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
   launch_trans<1>(trans_a, trans_b, epilogue, grid, s, a);
@@ -548,6 +589,7 @@ static int fill_group(int n, const MtamGemmDesc *d, GroupArgs &ga, int &blocks_o
     a.tiles_n = (q.N + BN - 1) / BN;
     a.heads = 0;
     a.sA0 = a.sA1 = a.sB0 = a.sB1 = a.sC0 = a.sC1 = 0;
+    a.A2 = a.B2 = nullptr; a.K2 = a.lda2 = a.ldb2 = a.vec2 = 0;
     ga.first[i] = blocks;
     blocks += a.tiles_n * ((q.M + BM - 1) / BM) * split;
   }

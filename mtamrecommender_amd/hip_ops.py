@@ -60,6 +60,18 @@ def gemm(a, b, c, trans_a=False, trans_b=False, epilogue=EPI_STORE, bias=None, a
     _lib.check(rc, "mtam_gemm_f32")
 
 
+def gemm_dual(a, b, a2, b2, c, trans_b=True, epilogue=EPI_STORE, bias=None, aux_in=None, aux_out=None):
+    """C = A op(B) + A2 op(B2) (+ epilogue); A [M,K], A2 [M,K2] row-major, B/B2 as in ``gemm``."""
+    lib = _lib.load()
+    M, K, K2 = a.shape[0], a.shape[1], a2.shape[1]
+    N = b.shape[0] if trans_b else b.shape[1]
+    ld_aux = aux_in.shape[-1] if aux_in is not None else 0
+    rc = lib.mtam_gemm_f32_dual(0, int(trans_b), M, N, K, _p(a), a.shape[-1], _p(b), b.shape[-1], K2, _p(a2),
+                                a2.shape[-1], _p(b2), b2.shape[-1], _p(c), c.shape[-1], epilogue, _p(bias),
+                                _p(aux_in), _p(aux_out), ld_aux, _stream())
+    _lib.check(rc, "mtam_gemm_f32_dual")
+
+
 def gemm_sq_partials(M, N):
     return _lib.load().mtam_gemm_sq_partials(M, N)
 

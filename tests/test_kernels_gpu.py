@@ -697,3 +697,21 @@ def test_gemm_store_sq_epilogue(ops):
     c2 = torch.zeros((M, N), device="cuda")
     ops.gemm(dev(a), dev(b), c2, trans_a=True)
     assert torch.equal(c, c2)
+
+
+def test_gemm_dual_source(ops):
+    """C = A B^T + A2 B2^T with the ACCUM2_MASK epilogue (the d_x product of the MTAM backward)."""
+    rng = np.random.default_rng(31)
+    M, N, K, K2 = 333, 128, 384, 256
+    a, b = rng.standard_normal((M, K)).astype(np.float32), rng.standard_normal((N, K)).astype(np.float32)
+    a2, b2 = rng.standard_normal((M, K2)).astype(np.float32), rng.standard_normal((N, K2)).astype(np.float32)
+    c0 = rng.standard_normal((M, N)).astype(np.float32)
+    add2 = rng.standard_normal((M, N)).astype(np.float32)
+    gate = rng.standard_normal((M, N)).astype(np.float32)
+    c, out = dev(c0).clone(), torch.zeros((M, N), device="cuda")
+    ops.gemm_dual(dev(a), dev(b), dev(a2), dev(b2), c, trans_b=True, epilogue=ops.EPI_ACCUM2_MASK,
+                  bias=dev(add2), aux_in=dev(gate), aux_out=out)
+    ref = c0.astype(np.float64) + add2 + a.astype(np.float64) @ b.T.astype(np.float64) \
+        + a2.astype(np.float64) @ b2.T.astype(np.float64)
+    assert rel_err(c.cpu().numpy(), ref) < 1e-5
+    assert rel_err(out.cpu().numpy(), np.where(gate > 0, ref, 0.0)) < 1e-5
