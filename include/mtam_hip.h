@@ -334,6 +334,30 @@ int mtam_softmax_ce_loss(const float *logits, int ld, const int32_t *target, int
                          const float *l2_partial, int n_l2, float reg, float ce_scale, float *loss,
                          void *stream);
 
+/* ------------------------------------------- bf16 scoring without logits (BASELINE.json configs[4])
+ * The same loss and gradients as the block above (Model/base_model.py:300-328, 290-297) computed from a
+ * bf16 copy of the item table with bf16 MFMA and fp32 accumulation, the [B, V] logits never stored:
+ *   E16 [V, 128] bf16 bits, P16 [mtam_score16_batch_pad(B), 128] bf16 bits (rows >= B zero) -- both made
+ *   by mtam_f32_to_bf16 (round to nearest even; n_dst >= n_src, the tail is zero-filled; counts % 4 == 0).
+ *   mtam_score16_lse    lse[b], ce[b] = lse[b] - <P16[b], E16[target[b]]>; partial: scratch of
+ *                       mtam_score16_partials(B, V) floats
+ *   mtam_score16_bwd    with G = (exp(score - lse) - onehot) * scale (rounded to bf16):
+ *                       d_pred [B, 128] += G E16 (fp32 atomics: the caller zeroes it),
+ *                       dE [V, 128] = G^T P16 (stored, every row), and if sq_partial != NULL (scratch of
+ *                       mtam_score16_sq_partials(V) floats) the per-wave sums of dE^2
+ *   mtam_score16_logits evaluation: logits [B, ld] fp32 for mtam_topk
+ */
+int mtam_f32_to_bf16(const float *src, size_t n_src, uint16_t *dst, size_t n_dst, void *stream);
+int mtam_score16_batch_pad(int B);
+int mtam_score16_partials(int B, int V);
+int mtam_score16_sq_partials(int V);
+int mtam_score16_lse(const uint16_t *E16, const uint16_t *P16, const int32_t *target, int B, int V,
+                     float *partial, float *lse, float *ce, void *stream);
+int mtam_score16_bwd(const uint16_t *E16, const uint16_t *P16, const float *lse, const int32_t *target, int B,
+                     int V, float scale, float *d_pred, float *dE, float *sq_partial, void *stream);
+int mtam_score16_logits(const uint16_t *E16, const uint16_t *P16, int B, int V, float *logits, long ld,
+                        void *stream);
+
 /* ------------------------------------------------------------------ top-K
  * tf.nn.top_k (Model/base_model.py:196-200): for every row the k largest
  * scores, descending, equal values -> lower index first.  k <= 64.

@@ -44,7 +44,8 @@ class MTAM(MTAMRec_model):
         self.path = TimeAwarePath(self.embedding.tables(), live, L, self.num_heads, NB,
                                   self.regulation_rate, self.FLAGS.max_gradient_norm,
                                   tf_compat_global_norm=self.FLAGS.tf_compat_global_norm, device=device,
-                                  optimizer=self.opt, variant=self.VARIANT)
+                                  optimizer=self.opt, variant=self.VARIANT,
+                                  score_dtype=getattr(self.FLAGS, "score_dtype", "f32"))
         self.summery()
 
     # weight injection for parity tests / checkpoint interchange (TF names)
@@ -62,6 +63,7 @@ class MTAM(MTAMRec_model):
             else:
                 raise KeyError(k)
         p.params.copy_(torch.from_numpy(p.layout.pack(dense)))
+        p.refresh_item16()
 
     def get_variables(self):
         out = dict(self.path.dense_tf())

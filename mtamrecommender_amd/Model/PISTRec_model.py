@@ -39,7 +39,7 @@ class Time_Aware_self_Attention_model(PISTRec_model):
         self.path = SelfAttentionPath(self.embedding.tables(), live, L, self.num_heads, NB,
                                       self.FLAGS.regulation_rate, self.FLAGS.max_gradient_norm,
                                       tf_compat_global_norm=self.FLAGS.tf_compat_global_norm, device=device,
-                                  optimizer=self.opt)
+                                      optimizer=self.opt, score_dtype=getattr(self.FLAGS, "score_dtype", "f32"))
         self.summery()
 
     set_variables = MTAM.set_variables

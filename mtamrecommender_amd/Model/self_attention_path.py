@@ -78,7 +78,7 @@ class SelfAttentionPath(TimeAwarePath):
         ops.seq_row_gather(bt.enc[NB], fd["seq_length"], -1, B, L, bt.long)
         hl = self.seg("head/ln")
         ops.layer_norm_fwd(bt.long, hl[0], hl[1], 1e-12, B, bt.pred, bt.ln_save if training else None)
-        ops.gemm(bt.pred, T["item"], bt.logits_store, trans_b=True)
+        self.score_forward(bt, training)
 
     # ---------------------------------------------------------------- backward
     def backward(self, bt):
@@ -88,15 +88,7 @@ class SelfAttentionPath(TimeAwarePath):
         gseg = lambda name: self.layout.view(G, name)
         part = bt.norm_partial
         sr = max(1, min(16, R // 256))
-        if self.tf_compat:
-            ops.gemm(bt.logits_store, bt.pred, self.g_tab["item"], trans_a=True, epilogue=ops.EPI_STORE_SQ,
-                     aux_out=part[self.nb_dense:], M=self.item_rows)
-        else:
-            ops.gemm(bt.logits_store, bt.pred, self.g_tab["item"], trans_a=True, M=self.item_rows)
-        # split-K over the catalog: ~64 slices at ml-1m sizes; for large catalogs enough slices (<= 1024) that
-        # 2,000+ workgroups stream the table (64 slices left one workgroup per CU: 43 TFLOP/s at V = 1 M)
-        split_v = max(1, min(64, (self.item_rows + 127) // 128), min(1024, self.item_rows // 2048))
-        ops.gemm(bt.logits_store, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v, K=self.item_rows)
+        self.score_backward(bt)
         ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_long, gseg("head/ln"))
         d_out, d_in = bt.d_a, bt.d_b
         ops.seq_row_scatter(bt.d_long, fd["seq_length"], -1, B, L, d_out)

@@ -89,6 +89,9 @@ class _Batch(object):
         self.logits_store = f(B, self.ld_logits)
         self.logits = self.logits_store[:, :V]
         self.lse, self.ce = f(B), f(B)
+        if path.score_dtype == "bf16":
+            self.pred16 = torch.zeros((ops.score16_batch_pad(B), D), dtype=torch.bfloat16, device=dev)
+            self.s16_partial = f(ops.score16_partials(B, V))
         self.ce_partial = torch.zeros(ops.softmax_ce_partials(B, V) + 4, dtype=torch.float32, device=dev)
         self.l2_partial = f(ops.emb_gather_partials(B, L))
         self.loss = f(3)
@@ -128,7 +131,8 @@ class TimeAwarePath(object):
     BATCH_CLASS = None       # set below
 
     def __init__(self, tables, dense_tf, L, num_heads, num_blocks, regulation_rate, max_gradient_norm,
-                 tf_compat_global_norm=True, device="cuda:0", optimizer="adam", variant=None):
+                 tf_compat_global_norm=True, device="cuda:0", optimizer="adam", variant=None,
+                 score_dtype="f32"):
         self.device = dev = torch.device(device)
         self.L, self.H, self.NB = L, num_heads, num_blocks
         self.reg, self.clip = float(regulation_rate), float(max_gradient_norm)
@@ -136,6 +140,12 @@ class TimeAwarePath(object):
         if optimizer not in ("adam", "sgd", "adadelta", "rmsprop"):
             raise ValueError("unknown optimizer %r" % (optimizer,))
         self.optimizer = optimizer
+        if score_dtype not in ("f32", "bf16"):
+            raise ValueError("score_dtype must be 'f32' or 'bf16' (got %r)" % (score_dtype,))
+        # "bf16" (BASELINE.json configs[4]): full-catalog scoring from a bf16 copy of the item table with
+        # bf16 MFMA / fp32 accumulation and no stored logits (csrc/score16.hip); fp32 master weights,
+        # gradients and optimizer slots, fp32 sequence side -- the autocast form of mixed precision
+        self.score_dtype = score_dtype
         from .variables import MTAM_VARIANTS
         if variant is not None:
             self.MODEL = variant
@@ -175,6 +185,11 @@ class TimeAwarePath(object):
         self.nb_dense = ops.sqnorm_blocks(self.n_dense)
         # the dense item gradient's squared norm comes out of its GEMM's epilogue (one partial per wave)
         self.nb_item = ops.gemm_sq_partials(self.item_rows, D)
+        self.item16 = None
+        if score_dtype == "bf16":
+            self.nb_item = ops.score16_sq_partials(self.item_rows)
+            self.item16 = torch.empty((self.item_rows, D), dtype=torch.bfloat16, device=dev)
+            self.refresh_item16()
         self.nb_all = max(ops.sqnorm_blocks(self.n_total), self.nb_dense + self.nb_item)
         self.scale = z(2)
         self.ticket = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -217,6 +232,46 @@ class TimeAwarePath(object):
         self.fill_host(bt, feed, lr)
         return bt.host_arena.to(self.device, non_blocking=False)
 
+    def refresh_item16(self):
+        """bf16 scoring copy of the item table <- fp32 master (after every update of the table)."""
+        if self.item16 is not None:
+            ops.f32_to_bf16(self.tables["item"].view(-1), self.item16.view(-1))
+
+    # ----------------------------------------------------------------- scoring (base_model.output)
+    def score_forward(self, bt, training):
+        """logits = pred . E^T (Model/base_model.py:309-312).  bf16 training keeps no logits: it goes
+        straight to lse / cross entropy."""
+        if self.score_dtype == "f32":
+            ops.gemm(bt.pred, self.tables["item"], bt.logits_store, trans_b=True)
+            return
+        V = self.item_rows
+        ops.f32_to_bf16(bt.pred.view(-1), bt.pred16.view(-1))
+        if training:
+            ops.score16_lse(self.item16, bt.pred16, bt.feed["target_item_id"], bt.B, V, bt.s16_partial, bt.lse, bt.ce)
+        else:
+            ops.score16_logits(self.item16, bt.pred16, bt.B, V, bt.logits_store, bt.ld_logits)
+
+    def score_backward(self, bt):
+        """dE (every row; its share of the TF global norm on the way out) and d_pred (accumulated)."""
+        part, V = bt.norm_partial, self.item_rows
+        sq = part[self.nb_dense:] if self.tf_compat else None
+        if self.score_dtype == "bf16":
+            gb = bt.B * self.world_size
+            ops.score16_bwd(self.item16, bt.pred16, bt.lse, bt.feed["target_item_id"], bt.B, V, 1.0 / gb,
+                            bt.d_pred, self.g_tab["item"], sq)
+            return
+        # dense item gradient dE = G^T pred (every row) and its share of the TF global norm
+        if self.tf_compat:
+            ops.gemm(bt.logits_store, bt.pred, self.g_tab["item"], trans_a=True, epilogue=ops.EPI_STORE_SQ,
+                     aux_out=sq, M=V)
+        else:
+            ops.gemm(bt.logits_store, bt.pred, self.g_tab["item"], trans_a=True, M=V)
+        # d_pred = G E: split-K over the catalog: ~64 slices at ml-1m sizes; for large catalogs enough
+        # slices (<= 1024) that 2,000+ workgroups stream the table (64 slices left one workgroup per CU:
+        # 43 TFLOP/s at V = 1 M)
+        split_v = max(1, min(64, (V + 127) // 128), min(1024, V // 2048))
+        ops.gemm(bt.logits_store, self.tables["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v, K=V)
+
     # ----------------------------------------------------------------- forward
     def forward(self, bt, training=True):
         """Model/MTAMRec_model.py:40-238 (the member is chosen by ``self.cfg``)."""
@@ -254,9 +309,11 @@ class TimeAwarePath(object):
                                        bt.attn_save[i] if training else None, head=head)
         else:
             ops.layer_norm_fwd(bt.short, hl[0], hl[1], 1e-12, B, bt.pred, bt.ln_save if training else None)
-        ops.gemm(bt.pred, T["item"], bt.logits_store, trans_b=True)
+        self.score_forward(bt, training)
 
     def loss_and_logit_grad(self, bt):
+        if self.score_dtype == "bf16":
+            return              # lse and cross entropy came out of score_forward; G is formed inside score_backward
         B, V = bt.B, self.item_rows
         gb = B * self.world_size
         # logits -> lse, ce; then d_logits in place
@@ -274,17 +331,7 @@ class TimeAwarePath(object):
         sr = max(1, min(16, R // 256))
         prob = lambda A, lda, Bm, ldb, name, M, N, K, s: dict(A=A, lda=lda, B=Bm, ldb=ldb, C=gseg(name),
                                                               ldc=N, M=M, N=N, K=K, split_k=s)
-        # dense item gradient dE = G^T pred (every row) and its share of the TF global norm
-        if self.tf_compat:
-            ops.gemm(bt.logits_store, bt.pred, self.g_tab["item"], trans_a=True, epilogue=ops.EPI_STORE_SQ,
-                     aux_out=part[self.nb_dense:], M=self.item_rows)
-        else:
-            ops.gemm(bt.logits_store, bt.pred, self.g_tab["item"], trans_a=True, M=self.item_rows)
-        # d_pred = G E -> head LN -> decoder blocks (last to first)
-        # split-K over the catalog: ~64 slices at ml-1m sizes; for large catalogs enough slices (<= 1024) that
-        # 2,000+ workgroups stream the table (64 slices left one workgroup per CU: 43 TFLOP/s at V = 1 M)
-        split_v = max(1, min(64, (self.item_rows + 127) // 128), min(1024, self.item_rows // 2048))
-        ops.gemm(bt.logits_store, T["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v, K=self.item_rows)
+        self.score_backward(bt)          # d_pred -> head LN -> decoder blocks (last to first)
         keys = bt.hs if cfg["keys"] == "gru" else bt.x
         d_keys = bt.d_hs if cfg["keys"] == "gru" else bt.d_x      # gradient of user_history
         problems, jobs = [], []
@@ -377,6 +424,7 @@ class TimeAwarePath(object):
             # sparse (row-skipping) region: category, position, user; the item gradient has every row
             ops.opt_update(self.optimizer, self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total,
                            self.scale, bt.feed["lr"], self.n_dense, self.tab_off["item"])
+        self.refresh_item16()
 
     def forward_backward_kernels(self, bt):
         self.forward(bt, training=True)

@@ -55,6 +55,13 @@ SIGNATURES = {
     "mtam_softmax_ce_loss": (c_int, [P, c_int, P, c_int, c_int, c_float, P, P, P, P, P, c_int, c_float, c_float,
                                      P, P]),
     "mtam_topk": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
+    "mtam_f32_to_bf16": (c_int, [P, c_size_t, P, c_size_t, P]),
+    "mtam_score16_batch_pad": (c_int, [c_int]),
+    "mtam_score16_partials": (c_int, [c_int, c_int]),
+    "mtam_score16_sq_partials": (c_int, [c_int]),
+    "mtam_score16_lse": (c_int, [P, P, P, c_int, c_int, P, P, P, P]),
+    "mtam_score16_bwd": (c_int, [P, P, P, P, c_int, c_int, c_float, P, P, P, P]),
+    "mtam_score16_logits": (c_int, [P, P, c_int, c_int, P, ctypes.c_long, P]),
     "mtam_sqnorm_blocks": (c_int, [c_size_t]),
     "mtam_sqnorm_partial": (c_int, [P, c_size_t, P, P]),
     "mtam_clip_scale": (c_int, [P, c_int, c_float, P, P, P, P]),

@@ -134,6 +134,9 @@ class model_parameter(object):
         # Additions of this build (not reference flags).
         f.DEFINE_boolean('tf_compat_global_norm', True,
                          'clip with TF1.14 IndexedSlices norm (SURVEY.md App D-5)')
+        f.DEFINE_string('score_dtype', 'f32',
+                        "'f32', or 'bf16': score the catalog from a bf16 copy of the item table with bf16 MFMA, "
+                        "fp32 accumulation and no stored logits (BASELINE.json configs[4]; csrc/score16.hip)")
         f.DEFINE_boolean('native_input', True,
                          'pack batches with libmtam_host.so on a worker thread (DataHandle/native_input.py) instead of '
                          'make_feed_dic_new per step')

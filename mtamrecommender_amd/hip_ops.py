@@ -249,6 +249,46 @@ def topk(scores, ld, rows, V, k, idx_out, val_out=None):
     _lib.check(lib.mtam_topk(_p(scores), ld, rows, V, k, _pi(idx_out), _p(val_out), _stream()), "mtam_topk")
 
 
+# ---- bf16 scoring (csrc/score16.hip): bf16 bit patterns travel as torch.bfloat16 tensors
+def _pb(t):
+    return _p(t, torch.bfloat16)
+
+
+def f32_to_bf16(src, dst):
+    """dst (bf16, numel >= src.numel()) = round-to-nearest-even(src); the tail of dst is zero-filled."""
+    lib = _lib.load()
+    _lib.check(lib.mtam_f32_to_bf16(_p(src), src.numel(), _pb(dst), dst.numel(), _stream()), "mtam_f32_to_bf16")
+
+
+def score16_batch_pad(B):
+    return _lib.load().mtam_score16_batch_pad(B)
+
+
+def score16_partials(B, V):
+    return _lib.load().mtam_score16_partials(B, V)
+
+
+def score16_sq_partials(V):
+    return _lib.load().mtam_score16_sq_partials(V)
+
+
+def score16_lse(E16, P16, target, B, V, partial, lse, ce):
+    lib = _lib.load()
+    _lib.check(lib.mtam_score16_lse(_pb(E16), _pb(P16), _pi(target), B, V, _p(partial), _p(lse), _p(ce), _stream()),
+               "mtam_score16_lse")
+
+
+def score16_bwd(E16, P16, lse, target, B, V, scale, d_pred, dE, sq_partial=None):
+    lib = _lib.load()
+    _lib.check(lib.mtam_score16_bwd(_pb(E16), _pb(P16), _p(lse), _pi(target), B, V, float(scale), _p(d_pred),
+                                    _p(dE), _p(sq_partial), _stream()), "mtam_score16_bwd")
+
+
+def score16_logits(E16, P16, B, V, logits, ld):
+    lib = _lib.load()
+    _lib.check(lib.mtam_score16_logits(_pb(E16), _pb(P16), B, V, _p(logits), ld, _stream()), "mtam_score16_logits")
+
+
 def sqnorm_blocks(n):
     return _lib.load().mtam_sqnorm_blocks(n)
 

@@ -181,7 +181,13 @@ def self_attention(w, enc, seq_len, t, num_heads, num_blocks):
 
 
 # ---------------------------------------------------------------- models
-def forward(model, w, feed, num_heads, num_blocks, regulation_rate, global_batch=None):
+def _bf16_straight_through(t):
+    """Value rounded to bf16 (round to nearest even), gradient of the identity: what a bf16 copy of an fp32
+    master weight (or an operand cast in front of a bf16 matrix product) means for training."""
+    return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
+
+
+def forward(model, w, feed, num_heads, num_blocks, regulation_rate, global_batch=None, score_dtype="f32"):
     """MTAM.build_model (Model/MTAMRec_model.py:61-92) or
     Time_Aware_self_Attention_model.build_model (Model/PISTRec_model.py:38-74),
     followed by base_model.output (Model/base_model.py:300-328).
@@ -190,6 +196,8 @@ def forward(model, w, feed, num_heads, num_blocks, regulation_rate, global_batch
     the gather gradient and the dense scoring gradient stay separable, as TF's
     IndexedSlices aggregation keeps them.
     ``global_batch``: mean divisor for data-parallel shards (default: local B).
+    ``score_dtype`` "bf16" (an option of this build, BASELINE.json configs[4]; not in the reference): both
+    operands of the scoring product are rounded to bf16, products and sums stay in the working precision.
     """
     user, x, item, cat, pos = get_embedding(w, feed)
     sl = feed["seq_length"]
@@ -220,7 +228,11 @@ def forward(model, w, feed, num_heads, num_blocks, regulation_rate, global_batch
         pred = layer_norm(long_term, w["UserHistoryEncoder/LayerNorm/beta"],
                           w["UserHistoryEncoder/LayerNorm/gamma"])
         l2 = 0.5 * (item ** 2).sum() + 0.5 * (cat ** 2).sum() + 0.5 * (pos ** 2).sum()
-    logits = torch.matmul(pred, w["embedding_layer/item_score"].t())
+    if score_dtype == "bf16":
+        logits = torch.matmul(_bf16_straight_through(pred),
+                              _bf16_straight_through(w["embedding_layer/item_score"]).t())
+    else:
+        logits = torch.matmul(pred, w["embedding_layer/item_score"].t())
     log_probs = torch.log_softmax(logits, dim=-1)
     one_hot = torch.nn.functional.one_hot(feed["target_item_id"], logits.shape[1]).to(logits.dtype)
     ce = -(log_probs * one_hot).sum(dim=-1)
@@ -245,7 +257,7 @@ def split_item_table(arrays, dtype, requires_grad=True):
 
 
 def loss_and_grads(model, arrays, feed, num_heads, num_blocks, regulation_rate, dtype=torch.float32,
-                   global_batch=None):
+                   global_batch=None, score_dtype="f32"):
     """tf.gradients(loss, trainable) -- Model/base_model.py:292.
 
     Returns (out, grads, slot_sq) where grads[name] is the dense (summed)
@@ -255,7 +267,7 @@ def loss_and_grads(model, arrays, feed, num_heads, num_blocks, regulation_rate, 
     """
     w = split_item_table(arrays, dtype)
     f = feed_to_torch(feed, dtype)
-    out = forward(model, w, f, num_heads, num_blocks, regulation_rate, global_batch)
+    out = forward(model, w, f, num_heads, num_blocks, regulation_rate, global_batch, score_dtype)
     for key in ("user", "item", "cat", "pos"):
         out[key].retain_grad()
     out["loss"].backward()
@@ -356,12 +368,12 @@ def apply_slot_optimizer(arrays, state, grads, scale, lr, feed):
 
 
 def train_step(model, arrays, state, feed, lr, num_heads, num_blocks, regulation_rate,
-               max_gradient_norm=1.0, tf_compat_norm=True, global_batch=None):
+               max_gradient_norm=1.0, tf_compat_norm=True, global_batch=None, score_dtype="f32"):
     """One ``sess.run([loss, merged, train_op])`` (Model/base_model.py:150-167,290-297):
     gradients -> clip_by_global_norm -> optimizer (Adam for an AdamState, else the SlotState's kind).
     Updates ``arrays``/``state`` in place."""
     out, grads, slot_sq = loss_and_grads(model, arrays, feed, num_heads, num_blocks,
-                                         regulation_rate, torch.float32, global_batch)
+                                         regulation_rate, torch.float32, global_batch, score_dtype)
     norm = np.float32(global_norm(grads, slot_sq, model, tf_compat_norm))
     c = np.float32(max_gradient_norm)
     scale = c * min(np.float32(1.0) / norm, np.float32(1.0) / c)          # clip_by_global_norm [TF1.14]

@@ -715,3 +715,73 @@ def test_gemm_dual_source(ops):
         + a2.astype(np.float64) @ b2.T.astype(np.float64)
     assert rel_err(c.cpu().numpy(), ref) < 1e-5
     assert rel_err(out.cpu().numpy(), np.where(gate > 0, ref, 0.0)) < 1e-5
+
+
+# ------------------------------------------------------------------ bf16 scoring without logits
+def test_f32_to_bf16_is_round_to_nearest_even(ops):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(4096).astype(np.float32) * np.float32(10.0) ** rng.integers(-20, 20, 4096).astype(np.float32)
+    x[:4] = [0.0, -0.0, 1.00390625, 1.01171875]          # exact halves between two bf16 values: ties to even
+    src = dev(x)
+    dst = torch.full((4096 + 512,), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.f32_to_bf16(src, dst)
+    assert torch.equal(dst[:4096].view(torch.int16), src.bfloat16().view(torch.int16))
+    assert bool((dst[4096:] == 0).all())
+
+
+def _score16_case(B, V, seed):
+    rng = np.random.default_rng(seed)
+    E = (rng.standard_normal((V, D)) * 0.2).astype(np.float32)
+    P = rng.standard_normal((B, D)).astype(np.float32)
+    target = rng.integers(0, V, B).astype(np.int32)
+    target[0] = V - 1
+    E16 = torch.empty((V, D), dtype=torch.bfloat16, device="cuda")
+    return E, P, target, E16
+
+
+@pytest.mark.parametrize("B,V", [(128, 3709), (100, 1000), (37, 63), (256, 70001), (130, 300007)])
+def test_score16_lse_logits_and_backward(ops, B, V):
+    """csrc/score16.hip against float64 products of the SAME bf16-rounded operands: the forward differs from
+    them by fp32 summation order only (1e-5); the backward also rounds G to bf16 (8 significant bits per
+    element, unbiased) before its two products, hence 4e-3 of the largest gradient entry."""
+    E, P, target, E16 = _score16_case(B, V, B + V)
+    Bp = ops.score16_batch_pad(B)
+    assert Bp % 128 == 0 and Bp >= B
+    ops.f32_to_bf16(dev(E).view(-1), E16.view(-1))
+    P16 = torch.empty((Bp, D), dtype=torch.bfloat16, device="cuda")
+    ops.f32_to_bf16(dev(P).view(-1), P16.view(-1))
+    tgt = dev(target)
+    lse = torch.zeros(B, device="cuda")
+    ce = torch.zeros(B, device="cuda")
+    partial = torch.zeros(ops.score16_partials(B, V), device="cuda")
+    ops.score16_lse(E16, P16, tgt, B, V, partial, lse, ce)
+
+    Er = E16.double()
+    Pr = P16[:B].double()
+    ref_logits = Pr @ Er.T
+    ref_lse = torch.logsumexp(ref_logits, 1)
+    ref_ce = ref_lse - ref_logits.gather(1, tgt.long()[:, None])[:, 0]
+    assert float((lse.double() - ref_lse).abs().max()) < 1e-5 * float(ref_lse.abs().max())
+    assert float((ce.double() - ref_ce).abs().max()) < 2e-5 * float(ref_lse.abs().max())
+
+    ld = (V + 3) // 4 * 4
+    logits = torch.full((B, ld), -77.0, device="cuda")
+    ops.score16_logits(E16, P16, B, V, logits, ld)
+    assert float((logits[:, :V].double() - ref_logits).abs().max()) < 1e-5 * float(ref_logits.abs().max())
+    assert bool((logits[:, V:] == -77.0).all())
+
+    scale = 1.0 / B
+    G = (torch.exp(ref_logits - ref_lse[:, None]))
+    G[torch.arange(B), tgt.long()] -= 1.0
+    G *= scale
+    ref_dpred = G @ Er
+    ref_dE = G.T @ Pr
+    d_pred = torch.zeros((B, D), device="cuda")
+    dE = torch.full((V, D), 5.0, device="cuda")
+    sq = torch.zeros(ops.score16_sq_partials(V), device="cuda")
+    ops.score16_bwd(E16, P16, lse, tgt, B, V, scale, d_pred, dE, sq)
+    assert float((d_pred.double() - ref_dpred).abs().max()) < 4e-3 * float(ref_dpred.abs().max())
+    assert float((dE.double() - ref_dE).abs().max()) < 4e-3 * float(ref_dE.abs().max())
+    # gradient rows of the softmax sum to ~0 over the catalog: dE^T 1 = pred^T (G 1) -- the bf16 rounding of G
+    # leaves a residue well below one rounding step of the largest entry
+    assert abs(float(sq.double().sum()) - float((dE.double() ** 2).sum())) < 1e-5 * float((dE.double() ** 2).sum())

@@ -20,7 +20,7 @@ GRAD_TOL = 5e-4       # relative max-norm per gradient tensor (fp32 kernels vs f
 
 
 def build(tmp_path, B, L, NB, H, items=300, cats=17, users=40, seed=5, id_dist="zipf", model_name="MTAM",
-          optimizer=None):
+          optimizer=None, score_dtype=None):
     from mtamrecommender_amd.config.model_parameter import model_parameter
     from mtamrecommender_amd.Embedding.Behavior_embedding_time_aware_attention import \
         Behavior_embedding_time_aware_attention
@@ -33,6 +33,8 @@ def build(tmp_path, B, L, NB, H, items=300, cats=17, users=40, seed=5, id_dist="
     FLAGS.checkpoint_path_dir = str(tmp_path)
     if optimizer is not None:
         FLAGS.optimizer = optimizer
+    if score_dtype is not None:
+        FLAGS.score_dtype = score_dtype
     cat = SyntheticCatalog(items, cats, users, seed=seed)
     emb = Behavior_embedding_time_aware_attention(True, users, items, cats, L, seed=seed)
     from mtamrecommender_amd.Model import MTAMRec_model as family
@@ -386,3 +388,59 @@ def test_mtam_family_trains_through_the_graph(hip_lib, tmp_path):
                            FLAGS.max_gradient_norm, True)
         loss, _ = model.train(model.sess, records, 1e-3)
         assert abs(loss - ref["loss"]) / abs(ref["loss"]) < 1e-4, step
+
+
+# ------------------------------------------------------------------ bf16 scoring (BASELINE.json configs[4])
+@pytest.mark.parametrize("model_name,B,L,items", [("MTAM", 128, 50, 3706), ("MTAM", 37, 20, 300),
+                                                   ("PISTRec", 64, 30, 1000)])
+def test_bf16_scoring_mode(hip_lib, tmp_path, model_name, B, L, items):
+    """FLAGS.score_dtype = 'bf16': logits-free bf16-MFMA scoring (csrc/score16.hip) inside the full step.
+    The oracle rounds both scoring operands to bf16 the same way and keeps everything else in float64.
+    Tolerances: the kernel's scores against float64 products of ITS OWN bf16 operands 1e-5 (summation
+    order only); against the oracle's scores 2e-3 of max |logit| (an element of pred that sits on a bf16
+    rounding boundary may round the other way: 2^-9 of one product); gradients 1e-2 of each tensor's largest
+    entry (G is rounded to bf16 before the two backward products); loss 1e-4."""
+    import oracle.mtam_oracle as O
+    NB, H = 1, 1
+    model, FLAGS, records = build(tmp_path, B, L, NB, H, items=items, cats=31, users=200, model_name=model_name,
+                                  score_dtype="bf16")
+    p = model.path
+    assert p.score_dtype == "bf16" and p.item16 is not None
+    arrays = {k: v.copy() for k, v in model.get_variables().items()}
+    feed = model.embedding.make_feed_dic_new(records)
+    assert torch.equal(p.item16.view(torch.int16), p.tables["item"].bfloat16().view(torch.int16))
+
+    # ---- evaluation forward: logits and top-K
+    bt = p.load_feed(feed)
+    p.eval_kernels(bt, 50)
+    out, grads, slot_sq = O.loss_and_grads(model_name, arrays, feed, H, NB, FLAGS.regulation_rate, torch.float64,
+                                           score_dtype="bf16")
+    pred = bt.pred.cpu().numpy()
+    assert rel(pred, out["pred"].detach().numpy()) < 2e-5
+    own = bt.pred.bfloat16().double() @ p.item16.double().T
+    assert float((bt.logits.double() - own).abs().max()) < 1e-5 * float(own.abs().max())
+    assert rel(bt.logits.cpu().numpy(), out["logits"].detach().numpy()) < 2e-3
+    assert np.array_equal(bt.topk_idx.cpu().numpy(), O.top_k(bt.logits.cpu().numpy(), 50))
+
+    # ---- one training step without the graph: loss, every gradient, the TF-style global norm
+    model.use_graph = False
+    loss, _ = model.train(model.sess, records, 1e-3)
+    ref_loss = float(out["loss"].detach())
+    assert abs(loss - ref_loss) / abs(ref_loss) < 1e-4
+    got = p.grads_tf()
+    for name, g in grads.items():
+        if g is not None:
+            assert rel(got[name], g) < 1e-2, name
+    ref_norm = O.global_norm(grads, slot_sq, model_name, True)
+    assert abs(float(p.scale[1]) - ref_norm) / ref_norm < 2e-3
+    # the scoring copy follows the master weights
+    assert torch.equal(p.item16.view(torch.int16), p.tables["item"].bfloat16().view(torch.int16))
+
+    # ---- through the hipGraph: the loss falls, the copy stays in step
+    model.use_graph = True
+    losses = [model.train(model.sess, records, 1e-3)[0] for _ in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < loss
+    torch.cuda.synchronize()
+    assert torch.equal(p.item16.view(torch.int16), p.tables["item"].bfloat16().view(torch.int16))
+    hr = model.metrics_topK(model.sess, records, 0, [1, 5, 10, 30, 50])
+    assert len(hr) == 10 and all(0.0 <= x <= 1.0 for x in hr)
