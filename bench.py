@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=1)
     ap.add_argument("--heads", type=int, default=1)
     ap.add_argument("--batch", type=int, default=128, help="sequences per GPU")
+    ap.add_argument("--score-dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: logits-free bf16-MFMA catalog scoring (BASELINE.json configs[4]); default fp32")
     args = ap.parse_args()
     global L, NB, H, B_PER_GPU
     L, NB, H, B_PER_GPU = args.seq_len, args.blocks, args.heads, args.batch
@@ -188,6 +190,7 @@ def main():
     FLAGS = model_parameter().get_parameter("MTAMb1_movielen").FLAGS
     FLAGS.num_blocks, FLAGS.num_heads, FLAGS.length_of_user_history = NB, H, L
     FLAGS.checkpoint_path_dir = "/tmp/mtam_bench_ckpt"
+    FLAGS.score_dtype = args.score_dtype
     shape = dict(ML1M)
     if args.items:
         shape.update(item_count=args.items, category_count=max(301, min(1000, args.items // 1000)))
@@ -263,7 +266,8 @@ def main():
             "metric": "training sequences/sec", "value": B_PER_GPU * world * args.steps / elapsed,
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.score_dtype == "f32" else "bf16 scoring operands, f32 accumulate and elsewhere",
+            "data": "synthetic",
             "config": {"workload": "%s training step, %s synthetic (%d items, %d categories, %d users), seq_len=%d "
                                    "emb=128 num_blocks=%d num_heads=%d, batch=%d per GPU"
                                    % ("MTAMRec" if args.model == "MTAM" else "PISTRec (Time_Aware_self_Attention_model)",

@@ -104,44 +104,52 @@ __global__ __launch_bounds__(256) void score16_lse_kernel(const uint16_t *__rest
   bf16x8 p1[8];
   load_pred_rows(p1, P, b, h);
   float m = -INFINITY, ssum = 0.f;
-  Stage st;
-  if (slab0 < slab1) {
-    stage_load(st, E, (long)slab0 * SLAB, V, tid);
-    stage_store(st, e_lds[0], tid);
-  }
-  __syncthreads();
-  for (int sl = slab0; sl < slab1; ++sl) {
-    const int cur = (sl - slab0) & 1;
-    const bool more = sl + 1 < slab1;
-    if (more) stage_load(st, E, (long)(sl + 1) * SLAB, V, tid);
+  // `ready` holds the next slab, `issue` receives the one after it: two slabs in flight per workgroup
+  // (one in flight left the kernel waiting on HBM latency: 4.8 TB/s of table bytes at 3 workgroups per CU)
+  auto step = [&](const int sl, const unsigned char *e_cur, unsigned char *e_next, Stage &ready, Stage &issue) {
+    if (sl + 2 < slab1) stage_load(issue, E, (long)(sl + 2) * SLAB, V, tid);
     f32x16 acc[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       acc[mb] = f32x16{0.f};
 #pragma unroll
       for (int s = 0; s < 8; ++s)
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e_frag(e_lds[cur], mb, s, r, h), p1[s], acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e_frag(e_cur, mb, s, r, h), p1[s], acc[mb], 0, 0, 0);
     }
+    const int vbase = sl * SLAB + 4 * h;
+    const int vlim = (sl * SLAB + SLAB <= V) ? 0x7fffffff : V;
     float mx = m;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int v = sl * SLAB + 32 * mb + acc_row(q, h);
-        const float x = (v < V) ? acc[mb][q] : -INFINITY;
+        const int v = vbase + 32 * mb + (q & 3) + 8 * (q >> 2);
+        const float x = (v < vlim) ? acc[mb][q] : -INFINITY;
         acc[mb][q] = x;
         mx = fmaxf(mx, x);
       }
     const float ref = (mx == -INFINITY) ? 0.f : mx;
+    const float nref = -ref * L2E;
     float add = 0.f;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) add += fast_exp2((acc[mb][q] - ref) * L2E);
-    ssum = ssum * fast_exp2((m - ref) * L2E) + add;
+      for (int q = 0; q < 16; ++q) add += fast_exp2(fmaf(acc[mb][q], L2E, nref));
+    ssum = ssum * fast_exp2(fmaf(m, L2E, nref)) + add;
     m = mx;
-    if (more) stage_store(st, e_lds[cur ^ 1], tid);
+    if (sl + 1 < slab1) stage_store(ready, e_next, tid);
     __syncthreads();
+  };
+  Stage sa, sb;
+  if (slab0 < slab1) {
+    stage_load(sa, E, (long)slab0 * SLAB, V, tid);
+    stage_store(sa, e_lds[0], tid);
+    if (slab0 + 1 < slab1) stage_load(sa, E, (long)(slab0 + 1) * SLAB, V, tid);
+  }
+  __syncthreads();
+  for (int sl = slab0; sl < slab1; sl += 2) {
+    step(sl, e_lds[0], e_lds[1], sa, sb);
+    if (sl + 1 < slab1) step(sl + 1, e_lds[1], e_lds[0], sb, sa);
   }
   // the two lane halves hold different catalog rows of the same batch row
   const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(ssum, 32, 64);
@@ -232,150 +240,185 @@ __global__ __launch_bounds__(256) void score16_logits_kernel(const uint16_t *__r
 
 // ------------------------------------------------------------------ backward: G, d_pred and dE in one pass
 struct BwdArgs {
-  const uint16_t *E, *P;
+  const uint16_t *E, *P;      // P, lse, target, d_pred: already moved to this launch's 128-row batch tile
   const float *lse;
   const int32_t *target;
-  int V, B, slabs_per_wg;
+  int V, Bt, slabs_per_wg;    // Bt = batch rows of this tile that exist (1 .. 128)
   float scale;
   float *d_pred, *dE, *sq_partial;
 };
 
-__global__ __launch_bounds__(256) void score16_bwd_kernel(BwdArgs p) {
+#ifndef S16_BWD_WAVES_PER_EU
+#define S16_BWD_WAVES_PER_EU 2      // 256 registers: two workgroups per CU (1.65 ms vs 2.24 ms at 10 M rows)
+#endif
+// S16_LAB_* are switches of the developer lab (tools/score16_lab.hip) that cut parts of the kernel out to
+// time the rest; the library is built with none of them.
+//
+// RMW: a batch tile after the first adds onto the dE rows the previous launch stored (B > 128).
+// Everything indexed by catalog row is 32-bit and branch-free: the first build of this kernel used 64-bit
+// row numbers and `valid && v < V` conditions, which the compiler turned into one exec-mask branch per
+// element (10,000 cycles per slab, 2.6 TB/s of the kernel's algorithmic bytes at one wave per SIMD).
+template <bool RMW>
+__global__ __launch_bounds__(256, S16_BWD_WAVES_PER_EU) void score16_bwd_kernel(BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char *e_lds0 = lds, *e_lds1 = lds + E_BYTES;
-  unsigned char *g_lds = lds + 2 * E_BYTES, *gt_lds = g_lds + G_BYTES;
+  unsigned char *const e_lds0 = lds, *const e_lds1 = lds + E_BYTES;
+  unsigned char *const g_lds = lds + 2 * E_BYTES, *const gt_lds = g_lds + G_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
   const int V = p.V;
   const int nslab = (V + SLAB - 1) / SLAB;
   const int slab0 = min((int)blockIdx.x * p.slabs_per_wg, nslab), slab1 = min(nslab, slab0 + p.slabs_per_wg);
-  const int ntile = (p.B + BT - 1) / BT;
   const int dcol = 32 * w + r;        // this lane's output column in both backward products
+  const int bcol = 32 * w + r;        // the batch row (of the tile) whose scores sit on this lane
+  const bool valid_b = bcol < p.Bt;
+  // G = exp2(score * log2 e + c_b) - [v == target] * scale, c_b = -lse * log2 e + log2 scale; a batch row
+  // that does not exist gets c_b = -inf and no target: G = 0 without a mask
+  const float c_b = valid_b ? fmaf(-p.lse[min(bcol, p.Bt - 1)], L2E, log2f(p.scale)) : -INFINITY;
+  const int t_b = valid_b ? min(max(p.target[min(bcol, p.Bt - 1)], 0), V - 1) : -1;
+  bf16x8 p1[8], p2[8];
+  load_pred_rows(p1, p.P, bcol, h);
+  // pred[k = b][n = d] fragments for dE (k-step s covers batch rows 16 s .. 16 s + 15 of the tile)
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    uint16_t u[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u[j] = p.P[(16 * s + 8 * h + j) * D + dcol];
+    u32x4 pk = {(uint32_t)u[0] | ((uint32_t)u[1] << 16), (uint32_t)u[2] | ((uint32_t)u[3] << 16),
+                (uint32_t)u[4] | ((uint32_t)u[5] << 16), (uint32_t)u[6] | ((uint32_t)u[7] << 16)};
+    p2[s] = __builtin_bit_cast(bf16x8, pk);
+  }
+  f32x16 dp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dp[i] = f32x16{0.f};
   float sq = 0.f;
 
-  for (int tile = 0; tile < ntile; ++tile) {
-    // Batch tiles beyond the first add onto the dE rows this same thread stored in the previous pass
-    // (same workgroup, same slabs, same lane -> no race).
-    const bool rmw = tile > 0, last_tile = tile == ntile - 1;
-    const long bbase = (long)tile * BT;
-    const long bcol = bbase + 32 * w + r;           // the batch row whose scores sit on this lane
-    const bool valid_b = bcol < p.B;
-    const float lse_b = valid_b ? p.lse[bcol] : 0.f;
-    const int t_b = valid_b ? min(max(p.target[bcol], 0), V - 1) : -1;
-    bf16x8 p1[8], p2[8];
-    load_pred_rows(p1, p.P, bcol, h);
-    // pred[k = b][n = d] fragments for dE (k-step s covers batch rows 16 s .. 16 s + 15 of the tile)
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      uint16_t u[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) u[j] = p.P[(bbase + 16 * s + 8 * h + j) * D + dcol];
-      u32x4 pk = {(uint32_t)u[0] | ((uint32_t)u[1] << 16), (uint32_t)u[2] | ((uint32_t)u[3] << 16),
-                  (uint32_t)u[4] | ((uint32_t)u[5] << 16), (uint32_t)u[6] | ((uint32_t)u[7] << 16)};
-      p2[s] = __builtin_bit_cast(bf16x8, pk);
-    }
-    f32x16 dp[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dp[i] = f32x16{0.f};
+  // lane-constant LDS addresses (the 4 h of the accumulator row map folded in)
+  unsigned char *const g_wr = g_lds + (4 * h) * G_PITCH + (32 * w + r) * 2;       // G[v][b], one element
+  unsigned char *const gt_wr = gt_lds + (32 * w + r) * GT_PITCH + (4 * h) * 2;    // G^T[b][v], four rows of v
+  const unsigned char *const g_rd = g_lds + r * G_PITCH + 16 * h;
+  const unsigned char *const gt_rd = gt_lds + r * GT_PITCH + 16 * h;
 
-    Stage st;
-    __syncthreads();        // the previous tile's last reads of the LDS buffers are done
-    if (slab0 < slab1) {
-      stage_load(st, p.E, (long)slab0 * SLAB, V, tid);
-      stage_store(st, e_lds0, tid);
+  // One slab.  `ready` holds the NEXT slab (loaded one step ago), `issue` receives the one after it: two
+  // slabs (32 KiB per workgroup) are in flight while this one is computed.
+  auto step = [&](const int sl, const unsigned char *e_cur, unsigned char *e_next, Stage &ready, Stage &issue) {
+    if (sl + 2 < slab1) stage_load(issue, p.E, (long)(sl + 2) * SLAB, V, tid);
+    const int vbase = sl * SLAB;
+    const bool full = vbase + SLAB <= V;
+    const int vlim = full ? 0x7fffffff : V;
+
+    // ---- S[v][b] for this wave's 32 batch rows, then G to LDS as bf16 in both orientations
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x16 acc = {0.f};
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e_frag(e_cur, mb, s, r, h), p1[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        bf16x4 gq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 32 * mb + 8 * q4 + i;           // + 4 h: catalog row of the slab
+          const int v = vbase + row + 4 * h;
+#ifdef S16_LAB_NO_EXP
+          float g = acc[4 * q4 + i] - ((v == t_b) ? p.scale : 0.f);
+#else
+          float g = fast_exp2(fmaf(acc[4 * q4 + i], L2E, c_b)) - ((v == t_b) ? p.scale : 0.f);
+#endif
+          g = (v < vlim) ? g : 0.f;
+          const __bf16 gb = (__bf16)g;
+          gq[i] = gb;
+          *reinterpret_cast<__bf16 *>(g_wr + row * G_PITCH) = gb;
+        }
+        // registers 4 q4 .. 4 q4 + 3 are catalog rows 8 q4 + 4 h + 0..3: contiguous in G^T[b][v]
+        *reinterpret_cast<bf16x4 *>(gt_wr + (32 * mb + 8 * q4) * 2) = gq;
+      }
     }
     __syncthreads();
-    for (int sl = slab0; sl < slab1; ++sl) {
-      const int cur = (sl - slab0) & 1;
-      const unsigned char *e_cur = cur ? e_lds1 : e_lds0;
-      unsigned char *e_next = cur ? e_lds0 : e_lds1;
-      const bool more = sl + 1 < slab1;
-      if (more) stage_load(st, p.E, (long)(sl + 1) * SLAB, V, tid);
-      const long vbase = (long)sl * SLAB;
 
-      // ---- S[v][b] for this wave's 32 batch rows, then G = (softmax - onehot) * scale, to LDS as bf16
+    // ---- dE[v][d] = sum_b G[v][b] pred[b][d]   (this wave: columns d = 32 w ..)
+#ifndef S16_LAB_NO_DE
+    float *const out = p.dE + ((size_t)vbase + 4 * h) * D + dcol;
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        f32x16 acc = {0.f};
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x16 acc = {0.f};
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e_frag(e_cur, mb, s, r, h), p1[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          bf16x4 gq;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int q = 4 * q4 + i;
-            const int vrow = 32 * mb + acc_row(q, h);
-            const long v = vbase + vrow;
-            float g = (fast_exp2((acc[q] - lse_b) * L2E) - ((v == t_b) ? 1.f : 0.f)) * p.scale;
-            g = (valid_b && v < V) ? g : 0.f;
-            const __bf16 gb = (__bf16)g;
-            gq[i] = gb;
-            *reinterpret_cast<__bf16 *>(g_lds + vrow * G_PITCH + (32 * w + r) * 2) = gb;
-          }
-          // registers 4 q4 .. 4 q4 + 3 are catalog rows 8 q4 + 4 h + 0..3: contiguous in G^T[b][v]
-          *reinterpret_cast<bf16x4 *>(gt_lds + (32 * w + r) * GT_PITCH + (32 * mb + 8 * q4 + 4 * h) * 2) = gq;
-        }
+      for (int s = 0; s < 8; ++s) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(g_rd + (32 * mb) * G_PITCH + 32 * s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, p2[s], acc, 0, 0, 0);
       }
-      __syncthreads();
-
-      // ---- dE[v][d] = sum_b G[v][b] pred[b][d]   (this wave: columns d = 32 w ..)
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        f32x16 acc = {0.f};
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8 *>(g_lds + (32 * mb + r) * G_PITCH + 32 * s + 16 * h);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, p2[s], acc, 0, 0, 0);
-        }
+      if (RMW) {
         float old[16];
-        if (rmw) {
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const long v = min(vbase + 32 * mb + acc_row(q, h), (long)V - 1);
-            old[q] = p.dE[v * D + dcol];
-          }
-        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const long v = vbase + 32 * mb + acc_row(q, h);
-          const float x = rmw ? acc[q] + old[q] : acc[q];
-          if (v < V) {
-            p.dE[v * D + dcol] = x;
-            if (last_tile) sq += x * x;
+          const int row = 32 * mb + (q & 3) + 8 * (q >> 2);
+          old[q] = out[(long)min(row, V - 1 - vbase - 4 * h) * D];      // clamped: rows past the end are not stored
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += old[q];
+      }
+      if (full) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          sq = fmaf(acc[q], acc[q], sq);
+#ifndef S16_LAB_NO_DE_STORE
+          out[(size_t)(32 * mb + (q & 3) + 8 * (q >> 2)) * D] = acc[q];
+#endif
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = 32 * mb + (q & 3) + 8 * (q >> 2);
+          if (vbase + row + 4 * h < V) {
+            sq = fmaf(acc[q], acc[q], sq);
+            out[(size_t)row * D] = acc[q];
           }
         }
       }
-
-      // ---- d_pred[b][d] += sum_v G[v][b] E[v][d]   (this wave: columns d = 32 w .., all 128 batch rows)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        uint16_t u[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          u[j] = *reinterpret_cast<const uint16_t *>(e_cur + (16 * s + 8 * h + j) * E_PITCH + dcol * 2);
-        u32x4 pk = {(uint32_t)u[0] | ((uint32_t)u[1] << 16), (uint32_t)u[2] | ((uint32_t)u[3] << 16),
-                    (uint32_t)u[4] | ((uint32_t)u[5] << 16), (uint32_t)u[6] | ((uint32_t)u[7] << 16)};
-        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-        for (int mblk = 0; mblk < 4; ++mblk) {
-          const bf16x8 a =
-              *reinterpret_cast<const bf16x8 *>(gt_lds + (32 * mblk + r) * GT_PITCH + 32 * s + 16 * h);
-          dp[mblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, dp[mblk], 0, 0, 0);
-        }
-      }
-      if (more) stage_store(st, e_next, tid);
-      __syncthreads();
     }
-    // flush this workgroup's share of d_pred
+#endif
+
+    // ---- d_pred[b][d] += sum_v G[v][b] E[v][d]   (this wave: columns d = 32 w .., all 128 batch rows)
+#ifndef S16_LAB_NO_DPRED
 #pragma unroll
-    for (int mblk = 0; mblk < 4; ++mblk)
+    for (int s = 0; s < 4; ++s) {
+      uint16_t u[8];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const long b = bbase + 32 * mblk + acc_row(q, h);
-        if (b < p.B) atomicAdd(p.d_pred + b * D + dcol, dp[mblk][q]);
+      for (int j = 0; j < 8; ++j)
+        u[j] = *reinterpret_cast<const uint16_t *>(e_cur + (16 * s + 8 * h + j) * E_PITCH + dcol * 2);
+      u32x4 pk = {(uint32_t)u[0] | ((uint32_t)u[1] << 16), (uint32_t)u[2] | ((uint32_t)u[3] << 16),
+                  (uint32_t)u[4] | ((uint32_t)u[5] << 16), (uint32_t)u[6] | ((uint32_t)u[7] << 16)};
+      const bf16x8 bfrag = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+      for (int mblk = 0; mblk < 4; ++mblk) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(gt_rd + (32 * mblk) * GT_PITCH + 32 * s);
+        dp[mblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, dp[mblk], 0, 0, 0);
       }
+    }
+#endif
+    if (sl + 1 < slab1) stage_store(ready, e_next, tid);
+    __syncthreads();
+  };
+
+  Stage sa, sb;
+  if (slab0 < slab1) {
+    stage_load(sa, p.E, (long)slab0 * SLAB, V, tid);
+    stage_store(sa, e_lds0, tid);
+    if (slab0 + 1 < slab1) stage_load(sa, p.E, (long)(slab0 + 1) * SLAB, V, tid);
   }
+  __syncthreads();
+  for (int sl = slab0; sl < slab1; sl += 2) {
+    step(sl, e_lds0, e_lds1, sa, sb);
+    if (sl + 1 < slab1) step(sl + 1, e_lds1, e_lds0, sb, sa);
+  }
+
+  // flush this workgroup's share of d_pred
+#pragma unroll
+  for (int mblk = 0; mblk < 4; ++mblk)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int b = 32 * mblk + acc_row(q, h);
+      if (b < p.Bt) atomicAdd(p.d_pred + b * D + dcol, dp[mblk][q]);
+    }
   if (p.sq_partial) {
     sq = wave_sum(sq);
     if (lane == 0) p.sq_partial[(size_t)blockIdx.x * 4 + w] = sq;
@@ -438,17 +481,31 @@ extern "C" int mtam_score16_bwd(const uint16_t *E16, const uint16_t *P16, const 
                                 int B, int V, float scale, float *d_pred, float *dE, float *sq_partial,
                                 void *stream) {
   MTAM_CHECK_ARG(E16 && P16 && lse && target && d_pred && dE, "score16_bwd: null argument");
-  MTAM_CHECK_ARG(B > 0 && V > 0, "score16_bwd: bad shape B=%d V=%d", B, V);
+  MTAM_CHECK_ARG(B > 0 && V > 0 && V < 0x7fffff00 && scale > 0.f, "score16_bwd: bad shape B=%d V=%d", B, V);
   MTAM_CHECK_ARG(mtam_aligned16(E16) && mtam_aligned16(P16), "score16_bwd: operands must be 16-byte aligned");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score16_bwd_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(score16_bwd_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(score16_bwd_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
     MTAM_CHECK_ARG(e == hipSuccess, "score16_bwd: cannot reserve %d bytes of LDS: %s", BWD_LDS, hipGetErrorString(e));
     attr_set = true;
   }
-  BwdArgs a{E16, P16, lse, target, V, B, slabs_per_wg_of(V), scale, d_pred, dE, sq_partial};
-  hipLaunchKernelGGL(score16_bwd_kernel, dim3(grid_of(V)), dim3(256), BWD_LDS, static_cast<hipStream_t>(stream), a);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // one launch per 128-row batch tile; launches on one stream run in order, so a later tile's
+  // read-modify-write of dE sees the earlier one's stores.  The squared norm comes from the last tile.
+  const int ntile = (B + BT - 1) / BT;
+  for (int tile = 0; tile < ntile; ++tile) {
+    const long b0 = (long)tile * BT;
+    BwdArgs a{E16, P16 + b0 * D, lse + b0, target + b0, V, (int)min((long)BT, B - b0), slabs_per_wg_of(V), scale,
+              d_pred + b0 * D, dE, tile == ntile - 1 ? sq_partial : nullptr};
+    if (tile == 0)
+      hipLaunchKernelGGL(score16_bwd_kernel<false>, dim3(grid_of(V)), dim3(256), BWD_LDS, st, a);
+    else
+      hipLaunchKernelGGL(score16_bwd_kernel<true>, dim3(grid_of(V)), dim3(256), BWD_LDS, st, a);
+  }
   MTAM_CHECK_LAUNCH("score16_bwd");
   return MTAM_OK;
 }
