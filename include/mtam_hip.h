@@ -400,6 +400,11 @@ int mtam_sqnorm_clip_scale(const float *g, size_t n, float *partials, int offset
 int mtam_adam_block(void);
 int mtam_adam(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
               const float *hyper, size_t sparse_begin, void *stream);
+/* mtam_adam that also writes the updated elements [copy_begin, n) as bf16 (round to nearest even) to
+ * copy16[0 .. n - copy_begin): the scoring copy of the item table (mtam_score16_*). */
+int mtam_adam_bf16copy(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
+                       const float *hyper, size_t sparse_begin, uint16_t *copy16, size_t copy_begin,
+                       void *stream);
 
 /* The other choices of base_model.init_optimizer (Model/base_model.py:71-80):
  * kind 0 GradientDescentOptimizer, 1 AdadeltaOptimizer (rho 0.95, eps 1e-8; slot1 = accum,

@@ -417,6 +417,11 @@ class TimeAwarePath(object):
         ops.sqnorm_clip_scale(self.flat_g, n_g, part, 0, n, self.clip, self.scale, bt.feed["lr"],
                               self.adam_state, self.ticket, bt.l2_partial, bt.l2_partial.numel(), bt.ce, bt.B,
                               self.reg, 1.0 / gb, bt.loss)
+        if self.optimizer == "adam" and self.item16 is not None:
+            # the bf16 scoring copy of the item table is refreshed by the same launch
+            ops.adam_bf16copy(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,
+                              self.adam_state, self.n_dense, self.item16, self.tab_off["item"])
+            return
         if self.optimizer == "adam":
             ops.adam(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,
                      self.adam_state, self.n_dense)

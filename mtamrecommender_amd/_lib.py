@@ -69,6 +69,7 @@ SIGNATURES = {
                                        c_float, c_float, P, P]),
     "mtam_adam_block": (c_int, []),
     "mtam_adam": (c_int, [P, P, P, P, c_size_t, P, P, c_size_t, P]),
+    "mtam_adam_bf16copy": (c_int, [P, P, P, P, c_size_t, P, P, c_size_t, P, c_size_t, P]),
     "mtam_opt_update": (c_int, [c_int, P, P, P, P, c_size_t, P, P, c_size_t, c_size_t, P]),
     "mtam_gemm_tn_atomic_grouped": (c_int, [c_int, P, P]),
     "mtam_colsum_atomic_multi": (c_int, [c_int, P, P]),

@@ -173,10 +173,15 @@ __global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restric
   }
 }
 
+// COPY: elements at or after copy_begin (the item table) are also written, rounded to nearest even, to the
+// bf16 scoring copy (csrc/score16.hip) -- 2 more bytes per element instead of a separate 6-byte pass.
+typedef __bf16 adam_bf16x4 __attribute__((ext_vector_type(4)));
+template <bool COPY>
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m,
                                                    float *__restrict__ v, const float *__restrict__ g, size_t n,
                                                    const float *__restrict__ scale,
-                                                   const float *__restrict__ hyper, size_t sparse_begin) {
+                                                   const float *__restrict__ hyper, size_t sparse_begin,
+                                                   uint16_t *__restrict__ copy16, size_t copy_begin) {
   const float sc = scale[0];
   const float lr_t = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
@@ -209,8 +214,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
       *reinterpret_cast<float4 *>(p + o) = pv;
       *reinterpret_cast<float4 *>(m + o) = mv;
       *reinterpret_cast<float4 *>(v + o) = vv;
+      if (COPY && o >= copy_begin) {
+        adam_bf16x4 c;
+        c.x = (__bf16)pv.x; c.y = (__bf16)pv.y; c.z = (__bf16)pv.z; c.w = (__bf16)pv.w;
+        *reinterpret_cast<adam_bf16x4 *>(copy16 + (o - copy_begin)) = c;
+      }
     } else {
-      for (size_t q = o; q < n && q < o + 4; ++q) step(p[q], m[q], v[q], g[q]);
+      for (size_t q = o; q < n && q < o + 4; ++q) {
+        step(p[q], m[q], v[q], g[q]);
+        if (COPY && q >= copy_begin) *reinterpret_cast<__bf16 *>(copy16 + (q - copy_begin)) = (__bf16)p[q];
+      }
     }
   }
 }
@@ -339,9 +352,26 @@ extern "C" int mtam_adam(float *p, float *m, float *v, const float *g, size_t n,
   MTAM_CHECK_ARG(sparse_begin >= n || sparse_begin % NORM_BLOCK == 0,
                  "adam: sparse_begin must be a multiple of %d (or >= n)", NORM_BLOCK);
   dim3 grid(mtam_sqnorm_blocks(n));
-  hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n, scale,
-                     hyper, sparse_begin);
+  hipLaunchKernelGGL(adam_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n, scale,
+                     hyper, sparse_begin, static_cast<uint16_t *>(nullptr), n);
   MTAM_CHECK_LAUNCH("adam");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_adam_bf16copy(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
+                                  const float *hyper, size_t sparse_begin, uint16_t *copy16, size_t copy_begin,
+                                  void *stream) {
+  MTAM_CHECK_ARG(p && m && v && g && scale && hyper && copy16 && n > 0, "adam_bf16copy: bad arguments");
+  MTAM_CHECK_ARG(mtam_aligned16(p) && mtam_aligned16(m) && mtam_aligned16(v) && mtam_aligned16(g) &&
+                     (reinterpret_cast<uintptr_t>(copy16) & 7u) == 0,
+                 "adam_bf16copy: buffers must be 16-byte aligned (the copy 8-byte)");
+  MTAM_CHECK_ARG(sparse_begin >= n || sparse_begin % NORM_BLOCK == 0,
+                 "adam_bf16copy: sparse_begin must be a multiple of %d (or >= n)", NORM_BLOCK);
+  MTAM_CHECK_ARG(copy_begin <= n && copy_begin % 4 == 0, "adam_bf16copy: copy_begin must be a multiple of 4");
+  dim3 grid(mtam_sqnorm_blocks(n));
+  hipLaunchKernelGGL(adam_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n, scale,
+                     hyper, sparse_begin, copy16, copy_begin);
+  MTAM_CHECK_LAUNCH("adam_bf16copy");
   return MTAM_OK;
 }
 

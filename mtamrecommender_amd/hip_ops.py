@@ -323,6 +323,12 @@ def adam(p, m, v, g, n, scale, hyper, sparse_begin):
                              _stream()), "mtam_adam")
 
 
+def adam_bf16copy(p, m, v, g, n, scale, hyper, sparse_begin, copy16, copy_begin):
+    lib = _lib.load()
+    _lib.check(lib.mtam_adam_bf16copy(_p(p), _p(m), _p(v), _p(g), n, _p(scale), _p(hyper), int(sparse_begin),
+                                      _pb(copy16), int(copy_begin), _stream()), "mtam_adam_bf16copy")
+
+
 OPT_KINDS = {"sgd": 0, "adadelta": 1, "rmsprop": 2}
 
 
