@@ -365,6 +365,12 @@ int mtam_score16_logits(const uint16_t *E16, const uint16_t *P16, int B, int V, 
  */
 int mtam_topk(const float *scores, int ld, int rows, int V, int k,
               int32_t *idx_out, float *val_out, void *stream);
+/* The same result for long rows in two launches: every row is cut into segments that one workgroup each
+ * reduces to k candidates, and a second pass picks the k of the row (ties still -> lower index).
+ * workspace: mtam_topk_workspace_bytes(rows, V, k) bytes (0 = rows too short to split; NULL = single pass). */
+size_t mtam_topk_workspace_bytes(int rows, int V, int k);
+int mtam_topk_ws(const float *scores, int ld, int rows, int V, int k, int32_t *idx_out, float *val_out,
+                 void *workspace, void *stream);
 
 /* ------------------------------------------------ clip_by_global_norm + Adam
  * tf.clip_by_global_norm + AdamOptimizer.apply_gradients

@@ -21,7 +21,10 @@ class _SABatch(_Batch):
         super(_SABatch, self).__init__(path, B)
         dev, L, NB, H = path.device, path.L, path.NB, path.H
         R = B * L
-        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        # zero-filled ONCE: some buffers are written only where a sample is alive (e.g. the GRU's saved
+        # state rows) and read whole by a GEMM whose other operand is zero there -- 0 x stale garbage must
+        # not be 0 x NaN (seen as a NaN weight gradient when the allocator handed out recycled memory)
+        f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
         self.enc = [self.x] + [f(R, D) for _ in range(NB)]
         self.qkv = [f(R, 3 * D) for _ in range(NB)]
         self.qt = [f(R, D) for _ in range(NB)]

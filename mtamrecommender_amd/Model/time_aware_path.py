@@ -62,7 +62,10 @@ class _Batch(object):
         dev, L, NB, H = path.device, path.L, path.NB, path.H
         R = B * L
         V = path.item_rows
-        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        # zero-filled ONCE: some buffers are written only where a sample is alive (e.g. the GRU's saved
+        # state rows) and read whole by a GEMM whose other operand is zero there -- 0 x stale garbage must
+        # not be 0 x NaN (seen as a NaN weight gradient when the allocator handed out recycled memory)
+        f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
         self.B, self.R = B, R
         # feed: ONE arena of 4-byte words at a fixed address (ids, times, learning rate), so that a
         # step needs one host->device (or device->device) copy and can be replayed from a hipGraph.
@@ -117,6 +120,7 @@ class _Batch(object):
         self.n_slot = ops.emb_scatter_partials(B, L)
         self.norm_partial = torch.zeros(path.nb_all + self.n_slot, dtype=torch.float32, device=dev)
         self.topk_idx = torch.zeros((B, 50), dtype=torch.int32, device=dev)
+        self.topk_ws = None         # candidate scratch of the two-level top-K (long rows only)
 
     def _view(self, arena, name):
         o, n, shape, dt = self.offsets[name]
@@ -445,7 +449,11 @@ class TimeAwarePath(object):
 
     def eval_kernels(self, bt, k=50):
         self.forward(bt, training=False)
-        ops.topk(bt.logits_store, bt.ld_logits, bt.B, self.item_rows, k, bt.topk_idx)
+        nbytes = ops.topk_workspace_bytes(bt.B, self.item_rows, k)
+        if nbytes and (bt.topk_ws is None or bt.topk_ws.numel() * 4 < nbytes):
+            bt.topk_ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+        ops.topk(bt.logits_store, bt.ld_logits, bt.B, self.item_rows, k, bt.topk_idx,
+                 workspace=bt.topk_ws if nbytes else None)
 
     # ------------------------------------------------------- weights in / out
     def dense_tf(self):

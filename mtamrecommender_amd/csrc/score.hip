@@ -264,8 +264,15 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
   return __uint_as_float(u);
 }
 
-__global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ scores, int ld, int V, int k,
-                                                   int32_t *__restrict__ idx_out, float *__restrict__ val_out) {
+// Long rows are cut into gridDim.y segments of `seg` elements (one workgroup each, indices reported
+// globally, missing entries of a short last segment filled with -inf / -1); a second launch of the same
+// kernel over the [rows, segments * k] candidate values picks the final k -- equal values keep the lower
+// POSITION, and positions are ordered by (segment, rank) = by global index among equal values -- and maps
+// its positions back through `idx_map`.  One workgroup per row left 128 of the 256 CUs idle with one
+// wave per SIMD: 80 ms for 128 rows of 50 M scores.
+__global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ scores, long ld, int V_row, int k,
+                                                   int32_t *__restrict__ idx_out, float *__restrict__ val_out,
+                                                   int seg, const int32_t *__restrict__ idx_map, float fill) {
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t scan[256];
   __shared__ uint32_t sel_bin, sel_above;
@@ -276,8 +283,11 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ sco
   __shared__ uint32_t eq_list[EQ_CAP];       // indices of the elements equal to the threshold (unordered)
 
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const float *s = scores + (size_t)row * ld;
-  const int kk = min(k, V);
+  const int seg0 = blockIdx.y * seg;                       // first element of this workgroup's segment
+  const int V = min(seg, V_row - seg0);
+  const float *s = scores + (size_t)row * ld + seg0;
+  const size_t out_row = (size_t)row * gridDim.y + blockIdx.y;
+  const int kk = max(0, min(k, V));
   // f(index, value) over the row: independent loads in flight per thread and trip -- four 16-byte
   // loads when the row starts on a 16-byte boundary (the model pads the logits row stride), else eight
   // 4-byte loads
@@ -427,8 +437,10 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ sco
     if (lane < k) {
       const uint32_t key = (uint32_t)(item >> 32);
       const uint32_t idx = 0xffffffffu - (uint32_t)(item & 0xffffffffu);
-      idx_out[(size_t)row * k + lane] = (lane < kk) ? (int32_t)idx : -1;
-      if (val_out) val_out[(size_t)row * k + lane] = (lane < kk) ? key_to_float(key) : 0.f;
+      int32_t out = -1;
+      if (lane < kk) out = idx_map ? idx_map[(size_t)row * ld + idx] : (int32_t)idx + seg0;
+      idx_out[out_row * k + lane] = out;
+      if (val_out) val_out[out_row * k + lane] = (lane < kk) ? key_to_float(key) : fill;
     }
   }
 }
@@ -508,12 +520,42 @@ extern "C" int mtam_softmax_ce_loss(const float *logits, int ld, const int32_t *
   return mtam_loss_reduce(l2_partial, n_l2, ce, B, reg, ce_scale, loss, stream);
 }
 
-extern "C" int mtam_topk(const float *scores, int ld, int rows, int V, int k, int32_t *idx_out,
-                         float *val_out, void *stream) {
+// segments per row for the two-level form (1 = single pass)
+static int topk_segments(int V) { return V < 262144 ? 1 : min(32, V / 65536); }
+static int topk_seg_len(int V) {
+  const int S = topk_segments(V);
+  return ((V + S - 1) / S + 1023) / 1024 * 1024;      // multiple of 1024: segments keep the row's 16-byte alignment
+}
+
+extern "C" size_t mtam_topk_workspace_bytes(int rows, int V, int k) {
+  if (rows <= 0 || V <= 0 || k <= 0 || topk_segments(V) == 1) return 0;
+  const int seg = topk_seg_len(V), S = (V + seg - 1) / seg;
+  return (size_t)rows * S * k * 8;
+}
+
+extern "C" int mtam_topk_ws(const float *scores, int ld, int rows, int V, int k, int32_t *idx_out, float *val_out,
+                            void *workspace, void *stream) {
   MTAM_CHECK_ARG(scores && idx_out && rows > 0 && V > 0 && ld >= V, "topk: bad arguments");
   MTAM_CHECK_ARG(k >= 1 && k <= 64, "topk: k must be in [1, 64] (got %d)", k);
-  hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), scores, ld, V, k,
-                     idx_out, val_out);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int seg = topk_seg_len(V), S = (V + seg - 1) / seg;
+  if (!workspace || topk_segments(V) == 1 || S == 1) {
+    hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(256), 0, st, scores, (long)ld, V, k, idx_out, val_out, V,
+                       static_cast<const int32_t *>(nullptr), 0.f);
+  } else {
+    MTAM_CHECK_ARG(rows <= 65535 * 1 && S <= 65535, "topk: too many segments");
+    float *cand_val = static_cast<float *>(workspace);
+    int32_t *cand_idx = reinterpret_cast<int32_t *>(cand_val + (size_t)rows * S * k);
+    hipLaunchKernelGGL(topk_kernel, dim3(rows, S), dim3(256), 0, st, scores, (long)ld, V, k, cand_idx, cand_val, seg,
+                       static_cast<const int32_t *>(nullptr), -INFINITY);
+    hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(256), 0, st, cand_val, (long)S * k, S * k, k, idx_out, val_out,
+                       S * k, cand_idx, 0.f);
+  }
   MTAM_CHECK_LAUNCH("topk");
   return MTAM_OK;
+}
+
+extern "C" int mtam_topk(const float *scores, int ld, int rows, int V, int k, int32_t *idx_out,
+                         float *val_out, void *stream) {
+  return mtam_topk_ws(scores, ld, rows, V, k, idx_out, val_out, nullptr, stream);
 }

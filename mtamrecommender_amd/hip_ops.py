@@ -244,9 +244,16 @@ def softmax_ce_loss(logits, ld, target, B, V, grad_scale, lse, ce, d_logits, par
     _lib.check(rc, "mtam_softmax_ce_loss")
 
 
-def topk(scores, ld, rows, V, k, idx_out, val_out=None):
+def topk_workspace_bytes(rows, V, k):
+    return _lib.load().mtam_topk_workspace_bytes(rows, V, k)
+
+
+def topk(scores, ld, rows, V, k, idx_out, val_out=None, workspace=None):
+    """workspace: a float32 tensor of topk_workspace_bytes(rows, V, k) bytes enables the two-level form
+    for long rows (same result)."""
     lib = _lib.load()
-    _lib.check(lib.mtam_topk(_p(scores), ld, rows, V, k, _pi(idx_out), _p(val_out), _stream()), "mtam_topk")
+    _lib.check(lib.mtam_topk_ws(_p(scores), ld, rows, V, k, _pi(idx_out), _p(val_out), _p(workspace), _stream()),
+               "mtam_topk")
 
 
 # ---- bf16 scoring (csrc/score16.hip): bf16 bit patterns travel as torch.bfloat16 tensors

@@ -561,6 +561,34 @@ def test_topk_bit_exact(ops, rows, V, k):
     assert np.array_equal(val.cpu().numpy()[:, :kk] + 0.0, np.take_along_axis(scores, ref, 1) + 0.0)
 
 
+@pytest.mark.parametrize("rows,V,k", [(5, 1000003, 50), (4, 262144, 20), (3, 2031617, 64)])
+def test_topk_two_level_matches_single_pass(ops, rows, V, k):
+    """Long rows with a workspace: segments -> candidates -> final k.  Same lists as the oracle's stable
+    sort, including ties that straddle segment boundaries, a constant row (all ties: indices 0..k-1) and a
+    last segment shorter than k (V = 31 segments x 65,536 + 1)."""
+    import oracle.mtam_oracle as O
+    rng = np.random.default_rng(V + k)
+    scores = rng.standard_normal((rows, V)).astype(np.float32)
+    scores[0, ::1000] = 9.5                                # equal maxima spread over every segment
+    scores[1] = np.round(scores[1] * 2) / 2                # heavy ties everywhere
+    scores[2] = 0.75                                       # a constant row
+    if rows > 3:
+        scores[3, -3:] = [40.0, 41.0, 40.0]                # winners at the very end of the row
+    nbytes = ops.topk_workspace_bytes(rows, V, k)
+    assert nbytes > 0
+    ws = torch.empty(nbytes // 4, device="cuda")
+    idx = torch.zeros((rows, k), dtype=torch.int32, device="cuda")
+    val = torch.zeros((rows, k), device="cuda")
+    ld = (V + 3) // 4 * 4
+    padded = np.full((rows, ld), 99.0, np.float32)         # the pad columns must not be read
+    padded[:, :V] = scores
+    ops.topk(dev(padded), ld, rows, V, k, idx, val, workspace=ws)
+    ref = O.top_k(scores, k)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(val.cpu().numpy() + 0.0, np.take_along_axis(scores, ref, 1) + 0.0)
+    assert ops.topk_workspace_bytes(rows, 3709, k) == 0
+
+
 # ------------------------------------------------------------ clip + Adam
 def test_clip_and_adam(ops):
     rng = np.random.default_rng(1)
