@@ -220,6 +220,25 @@ int mtam_tagru_bwd(const float *d_short, const float *d_hs, const float *x, cons
                    float *d_xproj, float *rh, float *d_xt, float *d_tvec_partial,
                    void *stream);
 
+/* The T-SeqRec cell (TimeAwareGRUCell_sigmoid, Model/Modules/time_aware_rnn.py:19-131, used by
+ * MTAM_with_T_SeqRec, Model/MTAMRec_model.py:275-306):
+ *   now  = x Wk1 + tanh(timenow  w1 + b1) Wt1 + bias1,  last = x Wk2 + tanh(timelast w2 + b2) Wt2 + bias2
+ *   h' = u h sigmoid(now) + (1 - u) c sigmoid(last)
+ * Neither gate depends on the state, so both are hoisted: xproj5 [B*L, 5 D] = (gates | candidate | now | last)
+ * pre-activations, input halves.  save6 [B*L, 6 D]; d_xproj5 [B*L, 5 D] receives all five gradients.
+ * mtam_tsr_time_inputs_fwd: tin [R, 2 D] = (tanh(timenow w1 + b1) | tanh(timelast w2 + b2)), tvec4 rows w1, b1,
+ * w2, b2.  mtam_tsr_time_inputs_bwd: out [R, 4 D] = (g_now timenow | g_now | g_last timelast | g_last) with
+ * g = d_tin (1 - tin^2); its column sums are the gradients of tvec4. */
+int mtam_tagru_seqrec_fwd(const float *xproj5, const int32_t *seq_len, const float *wh_g, const float *wh_c,
+                          int B, int L, float *hs, float *short_out, float *save6, void *stream);
+int mtam_tagru_seqrec_bwd(const float *d_short, const float *d_hs, const int32_t *seq_len, const float *wh_g,
+                          const float *wh_c, const float *save6, int B, int L, float *d_xproj5, float *rh,
+                          float *d_xt, float *d_tvec_partial, void *stream);
+int mtam_tsr_time_inputs_fwd(const float *timenow, const float *timelast, const float *tvec4, int R, float *tin,
+                             void *stream);
+int mtam_tsr_time_inputs_bwd(const float *d_tin, const float *tin, const float *timenow, const float *timelast,
+                             int R, float *out, void *stream);
+
 /* ------------------------------------------ time-aware attention, T_q = 1
  * One decoder block of vanilla_attention: Model/Modules/time_aware_attention.py:215-456
  * with t_querys_length = 1 (Model/MTAMRec_model.py:83-90), including the

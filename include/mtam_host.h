@@ -27,6 +27,7 @@ typedef struct {
   int user_id, item_list, category_list, position_list, target_item_id, seq_length;
   int time_list, timelast_list, target_item_time, lr;
   int words; /* total arena size in words */
+  int timenow_list; /* [B, L] floats, after lr (read by the T-SeqRec cell only) */
 } MtamArenaLayout;
 
 /* Row counts of the four tables (count + 3 each): ids outside [0, rows) are an error, as in TF. */

@@ -151,7 +151,7 @@ class BatchPacker(object):
             offsets, words = arena_layout(B, self.L)
             lay = _host_lib.ArenaLayout()
             for k in ("user_id", "item_list", "category_list", "position_list", "target_item_id", "seq_length",
-                      "time_list", "timelast_list", "target_item_time", "lr"):
+                      "time_list", "timelast_list", "target_item_time", "lr", "timenow_list"):
                 setattr(lay, k, offsets[k][0])
             lay.words = words
             pin = torch.cuda.is_available()

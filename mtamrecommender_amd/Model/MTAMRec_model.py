@@ -92,3 +92,9 @@ class MTAM_via_T_GRU(MTAM):
 class MTAM_via_rnn(MTAM):
     """Model/MTAMRec_model.py:206-238: as MTAM_via_T_GRU with the plain GRUCell."""
     VARIANT = "MTAM_via_rnn"
+
+
+class MTAM_with_T_SeqRec(MTAM):
+    """Model/MTAMRec_model.py:275-306: MTAM with the T-SeqRec cell (TimeAwareGRUCell_sigmoid) as the
+    short-term encoder."""
+    VARIANT = "MTAM_with_T_SeqRec"

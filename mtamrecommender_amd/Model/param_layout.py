@@ -3,6 +3,9 @@
 The kernels want the reference's variables packed differently from how TF 1.14
 creates them:
 
+* (T-SeqRec cell, time_aware_rnn.py:79-123) the input kernels of its two time gates join ``gru/wx`` as
+  columns 3D..5D and their biases join ``gru/bx``; the two time kernels form ``gru/tsr_wt`` [2,D,D], the
+  four time-input vectors ``gru/tsr_tvec`` [4,D];
 * the GRU ``gates/kernel`` [2D,2D] and ``candidate/kernel`` [2D,D]
   (Model/Modules/time_aware_rnn.py:166-185) are split into their input rows,
   packed side by side as ``gru/wx`` [D,3D] (one hoisted GEMM), and their
@@ -23,7 +26,7 @@ import collections
 
 import numpy as np
 
-from .variables import GRU_DEAD, GRU_USED, MTAM_VARIANTS, SHORT_LN, TIME_GATE, gru_scope, head_ln_scope
+from .variables import GRU_DEAD, GRU_USED, MTAM_VARIANTS, SHORT_LN, TIME_GATE, TSR_VEC, gru_scope, head_ln_scope
 
 Segment = collections.namedtuple("Segment", "name offset shape size")
 
@@ -40,10 +43,13 @@ class DenseLayout(object):
         self.cfg = MTAM_VARIANTS.get(model)
         segs = [("dense4emb/w", (2 * D, D))]
         if self.mtam:
-            segs += [("gru/wx", (D, 3 * D)), ("gru/bx", (3 * D,)), ("gru/wh_g", (D, 2 * D)),
+            xw = 5 if self.cfg["gru"] == "seqrec" else 3
+            segs += [("gru/wx", (D, xw * D)), ("gru/bx", (xw * D,)), ("gru/wh_g", (D, 2 * D)),
                      ("gru/wh_c", (D, D))]
             if self.cfg["gru"] == "time":
                 segs.append(("gru/tvec", (8, D)))
+            if self.cfg["gru"] == "seqrec":
+                segs += [("gru/tsr_wt", (2, D, D)), ("gru/tsr_tvec", (4, D))]
             if self.cfg["short_ln"]:
                 segs.append(("short/ln", (2, D)))
             if self.cfg["attention"]:
@@ -93,8 +99,15 @@ class DenseLayout(object):
         if self.mtam:
             GRU_SCOPE = gru_scope(self.model)
             Wg, Wc = tf_vars[GRU_SCOPE + "gates/kernel"], tf_vars[GRU_SCOPE + "candidate/kernel"]
-            put("gru/wx", np.concatenate([Wg[:D], Wc[:D]], axis=1))
-            put("gru/bx", np.concatenate([tf_vars[GRU_SCOPE + "gates/bias"], tf_vars[GRU_SCOPE + "candidate/bias"]]))
+            wx = [Wg[:D], Wc[:D]]
+            bx = [tf_vars[GRU_SCOPE + "gates/bias"], tf_vars[GRU_SCOPE + "candidate/bias"]]
+            if self.cfg["gru"] == "seqrec":
+                wx += [tf_vars[GRU_SCOPE + "_time_kernel_w1"], tf_vars[GRU_SCOPE + "_time_kernel_w2"]]
+                bx += [tf_vars[GRU_SCOPE + "_time_bias1"], tf_vars[GRU_SCOPE + "_time_bias2"]]
+                put("gru/tsr_wt", np.stack([tf_vars[GRU_SCOPE + "_time_kernel_t1"], tf_vars[GRU_SCOPE + "_time_kernel_t2"]]))
+                put("gru/tsr_tvec", np.stack([tf_vars[GRU_SCOPE + n] for n in TSR_VEC]))
+            put("gru/wx", np.concatenate(wx, axis=1))
+            put("gru/bx", np.concatenate(bx))
             put("gru/wh_g", Wg[D:])
             put("gru/wh_c", Wc[D:])
             if self.cfg["gru"] == "time":
@@ -137,8 +150,15 @@ class DenseLayout(object):
             wx, bx = get("gru/wx"), get("gru/bx")
             out[GRU_SCOPE + "gates/kernel"] = np.concatenate([wx[:, :2 * D], get("gru/wh_g")], axis=0)
             out[GRU_SCOPE + "gates/bias"] = bx[:2 * D]
-            out[GRU_SCOPE + "candidate/kernel"] = np.concatenate([wx[:, 2 * D:], get("gru/wh_c")], axis=0)
-            out[GRU_SCOPE + "candidate/bias"] = bx[2 * D:]
+            out[GRU_SCOPE + "candidate/kernel"] = np.concatenate([wx[:, 2 * D:3 * D], get("gru/wh_c")], axis=0)
+            out[GRU_SCOPE + "candidate/bias"] = bx[2 * D:3 * D]
+            if self.cfg["gru"] == "seqrec":
+                wt, tv4 = get("gru/tsr_wt"), get("gru/tsr_tvec")
+                out[GRU_SCOPE + "_time_kernel_w1"], out[GRU_SCOPE + "_time_kernel_w2"] = wx[:, 3 * D:4 * D], wx[:, 4 * D:]
+                out[GRU_SCOPE + "_time_bias1"], out[GRU_SCOPE + "_time_bias2"] = bx[3 * D:4 * D], bx[4 * D:]
+                out[GRU_SCOPE + "_time_kernel_t1"], out[GRU_SCOPE + "_time_kernel_t2"] = wt[0], wt[1]
+                for j, n in enumerate(TSR_VEC):
+                    out[GRU_SCOPE + n] = tv4[j]
             if self.cfg["gru"] == "time":
                 tv = get("gru/tvec")
                 for j, n in enumerate(GRU_USED):

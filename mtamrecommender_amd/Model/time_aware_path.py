@@ -29,7 +29,7 @@ from .param_layout import DenseLayout
 
 D = 128
 INT_FIELDS = ("user_id", "item_list", "category_list", "position_list", "target_item_id", "seq_length")
-FLOAT_FIELDS = ("time_list", "timelast_list", "target_item_time")
+FLOAT_FIELDS = ("time_list", "timelast_list", "target_item_time", "timenow_list")
 TABLES = ("category", "position", "user", "item")        # order inside the flat space (item last)
 MAX_GROUP = 16
 
@@ -46,7 +46,9 @@ def arena_layout(B, L):
               ("category_list", (B, L), torch.int32), ("position_list", (B, L), torch.int32),
               ("target_item_id", (B,), torch.int32), ("seq_length", (B,), torch.int32),
               ("time_list", (B, L), torch.float32), ("timelast_list", (B, L), torch.float32),
-              ("target_item_time", (B,), torch.float32), ("lr", (4,), torch.float32)]
+              ("target_item_time", (B,), torch.float32), ("lr", (4,), torch.float32),
+              # read by the T-SeqRec cell only (Model/Modules/time_aware_rnn.py:75-76,113-116)
+              ("timenow_list", (B, L), torch.float32)]
     offsets, o = {}, 0
     for name, shape, dt in fields:
         n = int(np.prod(shape))
@@ -77,8 +79,13 @@ class _Batch(object):
         # forward activations
         self.ic, self.pos, self.user = f(R, 2 * D), f(R, D), f(B, D)
         self.zr, self.x = f(R, D), f(R, D)
-        self.xproj, self.hs, self.short = f(R, 3 * D), f(R, D), f(B, D)
-        self.gru_save = f(R, 5 * D)
+        # x-projection width and saved-state slots: 5 D / 6 for the T-SeqRec cell (two hoisted time gates)
+        self.xw = xw = 5 if path.cfg["gru"] == "seqrec" else 3
+        self.nsave = nsave = 6 if path.cfg["gru"] == "seqrec" else 5
+        self.xproj, self.hs, self.short = f(R, xw * D), f(R, D), f(B, D)
+        self.gru_save = f(R, nsave * D)
+        if path.cfg["gru"] == "seqrec":
+            self.tin, self.d_tin, self.d_tvec4_rows = f(R, 2 * D), f(R, 2 * D), f(R, 4 * D)
         self.kv = f(R, 2 * NB * D)
         # decoder input: the short-term intent, layer-normed first in the via_* members
         self.short_n, self.short_ln_save = f(B, D), f(B, D + 1)
@@ -105,7 +112,7 @@ class _Batch(object):
         self.d_qt = [f(B, 2 * D) for _ in range(NB)]
         self.d_tp_partial = [f(B, 5 * L) for _ in range(NB)]
         self.d_ln_partial = [f(B, 2 * D) for _ in range(NB)]
-        self.d_xproj, self.rh = f(R, 3 * D), f(R, D)
+        self.d_xproj, self.rh = f(R, xw * D), f(R, D)
         self.d_tvec_partial = f(B, 8 * D)
         self.d_ic = f(R, 2 * D)
         # [d_pred | d_x]: cleared together by the step's first kernel when the decoder's key gradient goes
@@ -291,10 +298,24 @@ class TimeAwarePath(object):
         keys = bt.hs if cfg["keys"] == "gru" else bt.x        # user_history: what the decoder attends over
         if cfg["attention"] and cfg["keys"] == "x":           # keys/values of every block (before the GRU)
             ops.gemm(bt.x, self.seg("kv/w"), bt.kv, epilogue=ops.EPI_BIAS_RELU, bias=self.seg("kv/b"))
-        ops.gemm(bt.x, self.seg("gru/wx"), bt.xproj, epilogue=ops.EPI_BIAS, bias=self.seg("gru/bx"))
-        tvec = self.seg("gru/tvec") if cfg["gru"] == "time" else None
-        ops.tagru_fwd(bt.xproj, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
-                      self.seg("gru/wh_c"), tvec, B, L, bt.hs, bt.short, bt.gru_save if training else None)
+        if cfg["gru"] == "seqrec":
+            # TimeAwareGRUCell_sigmoid: gate and candidate input halves (columns 0 .. 3 D) and the two
+            # state-independent time gates  x Wk + tanh(t w + b) Wt + bias  (columns 3 D .. 5 D) in one buffer
+            wx, bx, wt = self.seg("gru/wx"), self.seg("gru/bx"), self.seg("gru/tsr_wt")
+            ops.tsr_time_inputs_fwd(fd["timenow_list"], fd["timelast_list"], self.seg("gru/tsr_tvec"), R, bt.tin)
+            ops.gemm(bt.x, wx, bt.xproj, epilogue=ops.EPI_BIAS, bias=bx, N=3 * D)
+            for j in range(2):
+                ops.gemm(bt.x, wx.view(-1)[(3 + j) * D:], bt.xproj.view(-1)[(3 + j) * D:], epilogue=ops.EPI_BIAS,
+                         bias=bx[(3 + j) * D:], N=D, K=D, ldb=5 * D, ldc=5 * D)
+                ops.gemm(bt.tin.view(-1)[j * D:], wt[j], bt.xproj.view(-1)[(3 + j) * D:], epilogue=ops.EPI_ACCUM,
+                         M=R, N=D, K=D, lda=2 * D, ldc=5 * D)
+            ops.tagru_seqrec_fwd(bt.xproj, fd["seq_length"], self.seg("gru/wh_g"), self.seg("gru/wh_c"), B, L,
+                                 bt.hs, bt.short, bt.gru_save if training else None)
+        else:
+            ops.gemm(bt.x, self.seg("gru/wx"), bt.xproj, epilogue=ops.EPI_BIAS, bias=self.seg("gru/bx"))
+            tvec = self.seg("gru/tvec") if cfg["gru"] == "time" else None
+            ops.tagru_fwd(bt.xproj, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
+                          self.seg("gru/wh_c"), tvec, B, L, bt.hs, bt.short, bt.gru_save if training else None)
         if cfg["short_ln"]:
             sl = self.seg("short/ln")
             ops.layer_norm_fwd(bt.short, sl[0], sl[1], 1e-12, B, bt.short_n, bt.short_ln_save if training else None)
@@ -371,14 +392,29 @@ class TimeAwarePath(object):
             d_short = bt.d_short
         # GRU back through time (its time-gate path goes to d_xt); with the GRU outputs as keys their
         # gradient enters every step
-        tvec = self.seg("gru/tvec") if cfg["gru"] == "time" else None
-        ops.tagru_bwd(d_short, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
-                      self.seg("gru/wh_c"), tvec, bt.gru_save, B, L, bt.d_xproj, bt.rh, bt.d_xt,
-                      bt.d_tvec_partial, d_hs=bt.d_hs if cfg["keys"] == "gru" else None)
-        problems = [prob(bt.x, D, bt.d_xproj, 3 * D, "gru/wx", D, 3 * D, R, sr),
-                    prob(bt.gru_save.view(-1)[4 * D:], 5 * D, bt.d_xproj, 3 * D, "gru/wh_g", D, 2 * D, R, sr),
-                    prob(bt.rh, D, bt.d_xproj.view(-1)[2 * D:], 3 * D, "gru/wh_c", D, D, R, sr)] + problems
-        jobs = [(bt.d_xproj, R, 3 * D, 3 * D, gseg("gru/bx"))] + jobs
+        xw, ns = bt.xw * D, bt.nsave * D
+        if cfg["gru"] == "seqrec":
+            ops.tagru_seqrec_bwd(d_short, fd["seq_length"], self.seg("gru/wh_g"), self.seg("gru/wh_c"), bt.gru_save,
+                                 B, L, bt.d_xproj, bt.rh, bt.d_xt, bt.d_tvec_partial,
+                                 d_hs=bt.d_hs if cfg["keys"] == "gru" else None)
+            # back through the two time kernels and the tanh time inputs
+            wt, g_wt = self.seg("gru/tsr_wt"), gseg("gru/tsr_wt")
+            for j in range(2):
+                ops.gemm(bt.d_xproj.view(-1)[(3 + j) * D:], wt[j], bt.d_tin.view(-1)[j * D:], trans_b=True,
+                         M=R, N=D, K=D, lda=5 * D, ldc=2 * D)
+                problems.append(dict(A=bt.tin.view(-1)[j * D:], lda=2 * D, B=bt.d_xproj.view(-1)[(3 + j) * D:],
+                                     ldb=5 * D, C=g_wt[j], ldc=D, M=D, N=D, K=R, split_k=sr))
+            ops.tsr_time_inputs_bwd(bt.d_tin, bt.tin, fd["timenow_list"], fd["timelast_list"], R, bt.d_tvec4_rows)
+            jobs.append((bt.d_tvec4_rows, R, 4 * D, 4 * D, gseg("gru/tsr_tvec").view(-1)))
+        else:
+            tvec = self.seg("gru/tvec") if cfg["gru"] == "time" else None
+            ops.tagru_bwd(d_short, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
+                          self.seg("gru/wh_c"), tvec, bt.gru_save, B, L, bt.d_xproj, bt.rh, bt.d_xt,
+                          bt.d_tvec_partial, d_hs=bt.d_hs if cfg["keys"] == "gru" else None)
+        problems = [prob(bt.x, D, bt.d_xproj, xw, "gru/wx", D, xw, R, sr),
+                    prob(bt.gru_save.view(-1)[4 * D:], ns, bt.d_xproj, xw, "gru/wh_g", D, 2 * D, R, sr),
+                    prob(bt.rh, D, bt.d_xproj.view(-1)[2 * D:], xw, "gru/wh_c", D, D, R, sr)] + problems
+        jobs = [(bt.d_xproj, R, xw, xw, gseg("gru/bx"))] + jobs
         if cfg["gru"] == "time":
             jobs.append((bt.d_tvec_partial, B, 8 * D, 8 * D, gseg("gru/tvec").view(-1)))
         # d_x (+)= d_xproj . Wx^T + d_xt, d_z = d_x where relu(z) > 0; then d[item|cat].  d_x already holds the

@@ -22,12 +22,13 @@ import numpy as np
 
 GRU_SCOPE = "ShortTermIntentEncoder/rnn/multi_rnn_cell/cell_0/time_aware_gru_cell_decay_new/"
 PLAIN_GRU_SCOPE = "ShortTermIntentEncoder/rnn/multi_rnn_cell/cell_0/gru_cell/"      # tf GRUCell (gru.py:13-39)
+TSR_SCOPE = "ShortTermIntentEncoder/rnn/multi_rnn_cell/cell_0/time_aware_gru_cell_sigmoid/"   # time_aware_rnn.py:19-131
 SHORT_LN = "ShortTermIntentEncoder/LayerNorm/"
 
 # The MTAM family (Model/MTAMRec_model.py:40-306): which recurrent cell encodes the short-term intent,
 # what the decoder attends over, and where layer norms sit.  The three members that need other
 # kernels are not built: MTAM_no_time_aware_att (non-time-aware attention with live dropout,
-# SURVEY.md F8), MTAM_hybird (output_concat head), MTAM_with_T_SeqRec (TimeAwareGRUCell_sigmoid).
+# SURVEY.md F8) and MTAM_hybird (output_concat head; never dispatched by train_process.py).
 MTAM_VARIANTS = {
     # name: (gru cell, attention keys, layer_norm on the short-term intent, attention decoder)
     "MTAM": dict(gru="time", keys="x", short_ln=False, attention=True),                       # :61-92
@@ -35,11 +36,12 @@ MTAM_VARIANTS = {
     "MTAM_no_time_aware_rnn": dict(gru="plain", keys="x", short_ln=False, attention=True),     # :93-127
     "MTAM_via_T_GRU": dict(gru="time", keys="gru", short_ln=True, attention=True),             # :167-204
     "MTAM_via_rnn": dict(gru="plain", keys="gru", short_ln=True, attention=True),              # :206-238
+    "MTAM_with_T_SeqRec": dict(gru="seqrec", keys="x", short_ln=False, attention=True),        # :275-306
 }
 
 
 def gru_scope(variant):
-    return GRU_SCOPE if MTAM_VARIANTS[variant]["gru"] == "time" else PLAIN_GRU_SCOPE
+    return {"time": GRU_SCOPE, "plain": PLAIN_GRU_SCOPE, "seqrec": TSR_SCOPE}[MTAM_VARIANTS[variant]["gru"]]
 
 
 def head_ln_scope(variant):
@@ -50,6 +52,11 @@ GRU_USED = ("_time_kernel_w1", "_time_kernel_b1", "_time_history_w1", "_time_w1"
             "_time_b1", "_time_kernel_w2", "_time_w12", "_time_b12")
 GRU_DEAD = ("_time_history_b1", "_time_kernel_b2", "_time_history_w2", "_time_history_b2",
             "_time_w2", "_time_b2")
+# TimeAwareGRUCell_sigmoid (time_aware_rnn.py:79-106): [D] vectors of the two time inputs, then per gate
+# an input kernel, a time kernel (both [D, D]) and a bias
+TSR_VEC = ("_time_input_w1", "_time_input_bias1", "_time_input_w2", "_time_input_bias2")
+TSR_MAT = ("_time_kernel_w1", "_time_kernel_t1", "_time_kernel_w2", "_time_kernel_t2")
+TSR_BIAS = ("_time_bias1", "_time_bias2")
 TIME_GATE = ("_time_input_w1", "_time_input_b1", "time_output_w1", "time_output_w2",
              "time_output_b")
 
@@ -102,6 +109,11 @@ def mtam_dense_specs(D, L, num_blocks, variant="MTAM"):
             specs.append(VarSpec(G + name, (D,), _glorot((D,)), True))
         for name in GRU_DEAD:
             specs.append(VarSpec(G + name, (D,), _glorot((D,)), False))
+    if cfg["gru"] == "seqrec":
+        for name in TSR_VEC + TSR_BIAS:
+            specs.append(VarSpec(G + name, (D,), _glorot((D,)), True))
+        for name in TSR_MAT:
+            specs.append(VarSpec(G + name, (D, D), _glorot((D, D)), True))
     if cfg["short_ln"]:
         specs.append(VarSpec(SHORT_LN + "beta", (D,), ("const", 0.0), True))
         specs.append(VarSpec(SHORT_LN + "gamma", (D,), ("const", 1.0), True))

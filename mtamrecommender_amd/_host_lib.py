@@ -9,7 +9,8 @@ P = c_void_p
 
 class ArenaLayout(ctypes.Structure):
     _fields_ = [(k, c_int) for k in ("user_id", "item_list", "category_list", "position_list", "target_item_id",
-                                     "seq_length", "time_list", "timelast_list", "target_item_time", "lr", "words")]
+                                     "seq_length", "time_list", "timelast_list", "target_item_time", "lr", "words",
+                                     "timenow_list")]
 
 
 class TableRows(ctypes.Structure):

@@ -37,6 +37,10 @@ SIGNATURES = {
                                          P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
     "mtam_tagru_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "mtam_tagru_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
+    "mtam_tagru_seqrec_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),
+    "mtam_tagru_seqrec_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
+    "mtam_tsr_time_inputs_fwd": (c_int, [P, P, P, c_int, P, P]),
+    "mtam_tsr_time_inputs_bwd": (c_int, [P, P, P, P, c_int, P, P]),
     "mtam_ta_attn_decode_save_floats": (c_int, [c_int, c_int]),
     "mtam_ta_attn_decode_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P,
                                         c_int, c_int, c_int, P, P, P, P, P, P, P]),

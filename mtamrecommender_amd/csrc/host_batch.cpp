@@ -303,6 +303,7 @@ extern "C" int mtam_pack_batch(const MtamRecordSet *rs, const int64_t *index, in
     memcpy(arena + lay->position_list + row, po, sizeof(int32_t) * n);
     memcpy(farena + lay->time_list + row, rs->time.data() + o, sizeof(float) * n);
     memcpy(farena + lay->timelast_list + row, rs->timelast.data() + o, sizeof(float) * n);
+    memcpy(farena + lay->timenow_list + row, rs->timenow.data() + o, sizeof(float) * n);
   }
   farena[lay->lr] = lr;
   return 0;

@@ -23,11 +23,16 @@ constexpr int NW = 8;  // waves per workgroup
 // tvec rows
 enum { KW1 = 0, KB1, HW1, W1, B1, KW2, W12, B12, NTV };
 
+// ldx = floats per xproj row: 3 D (gate | gate | candidate), or 5 D for the T-SeqRec cell
+// (TimeAwareGRUCell_sigmoid, Model/Modules/time_aware_rnn.py:19-131), whose two time gates do not depend
+// on the state: their pre-activations  x Wk + tanh(t w + b) Wt + bias  are hoisted into columns 3 D .. 5 D
+// of the same projection, and the step is  h' = u h sigmoid(now) + (1 - u) c sigmoid(last).
+// The saved state then has a sixth slot (the `now` gate).
 struct FwdArgs {
   const float *xproj, *x, *timelast;
   const int32_t *seq_len;
   const float *wh_g, *wh_c, *tvec;
-  int B, L;
+  int B, L, ldx;
   float *hs, *short_out, *save;
 };
 
@@ -36,6 +41,7 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
   __shared__ __attribute__((aligned(16))) float rh_s[D];
   __shared__ float u_s[D];
   __shared__ float T_s[D];
+  __shared__ float N_s[D];
   __shared__ float pg[NW][2 * D];
   __shared__ float pc[NW][D];
 
@@ -61,26 +67,29 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
   //   threads 256..383  time gate T (needs only x_t, dt and the OLD state: off the critical path)
   const int col = tid & (D - 1);
   // tvec == nullptr: the plain tf GRUCell (Model/Modules/gru.py:13-39) -- no time gate, T = 1
-  const bool plain = p.tvec == nullptr;
+  const bool seqrec = p.ldx == 5 * D;
+  const bool plain = p.tvec == nullptr && !seqrec;
   const bool is_T = !plain && (tid >= 2 * D) && (tid < 3 * D);
+  const int ldx = p.ldx, nsave = seqrec ? 6 : 5;
   float tv[NTV];
 #pragma unroll
-  for (int i = 0; i < NTV; ++i) tv[i] = (is_T) ? p.tvec[i * D + col] : 0.f;
+  for (int i = 0; i < NTV; ++i) tv[i] = (is_T && !seqrec) ? p.tvec[i * D + col] : 0.f;
 
   if (tid < D) {
     h_s[tid] = 0.f;
     T_s[tid] = 1.f;
+    N_s[tid] = 1.f;
   }
 
   // software prefetch of step t's inputs (independent of the recurrence)
   float n_a = 0.f, n_b = 0.f;
   auto prefetch = [&](int t) {
     const size_t r = row0 + t;
-    if (tid < 2 * D) n_a = p.xproj[r * (3 * D) + tid];             // gate pre-activation, input half
-    if (tid < D) n_b = p.xproj[r * (3 * D) + 2 * D + tid];         // candidate pre-activation, input half
+    if (tid < 2 * D) n_a = p.xproj[r * ldx + tid];             // gate pre-activation, input half
+    if (tid < D) n_b = p.xproj[r * ldx + 2 * D + tid];         // candidate pre-activation, input half
     if (is_T) {
-      n_a = p.x[r * D + col];
-      n_b = p.timelast[r];
+      n_a = seqrec ? p.xproj[r * ldx + 3 * D + col] : p.x[r * D + col];
+      n_b = seqrec ? p.xproj[r * ldx + 4 * D + col] : p.timelast[r];
     }
   };
   if (steps > 0) prefetch(0);
@@ -121,10 +130,15 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
         u_s[tid - D] = s;
       }
     } else if (is_T) {
-      const float h = h_s[col];
-      const float tw = fmaxf(in_a * tv[KW1] + tv[KB1] + h * tv[HW1], 0.f);
-      const float ts = fmaxf(tv[W1] * in_b + tv[B1], 0.f);
-      T_s[col] = fast_sigmoid(tv[KW2] * tw + tv[W12] * ts + tv[B12]);
+      if (seqrec) {
+        N_s[col] = fast_sigmoid(in_a);
+        T_s[col] = fast_sigmoid(in_b);
+      } else {
+        const float h = h_s[col];
+        const float tw = fmaxf(in_a * tv[KW1] + tv[KB1] + h * tv[HW1], 0.f);
+        const float ts = fmaxf(tv[W1] * in_b + tv[B1], 0.f);
+        T_s[col] = fast_sigmoid(tv[KW2] * tw + tv[W12] * ts + tv[B12]);
+      }
     }
     __syncthreads();
     // phase 2: candidate pre-activation, recurrent half on r*h (2 columns per lane)
@@ -146,14 +160,15 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
 #pragma unroll
       for (int q = 0; q < NW; ++q) cp += pc[q][tid];
       const float c = fast_tanh(cp);
-      const float h = h_s[tid], u = u_s[tid], T = T_s[tid];
-      const float hn = u * h + (1.f - u) * c * T;
+      const float h = h_s[tid], u = u_s[tid], T = T_s[tid], N = N_s[tid];
+      const float hn = u * h * N + (1.f - u) * c * T;
       h_s[tid] = hn;
       const size_t r = row0 + t;
       p.hs[r * D + tid] = hn;
       if (p.save) {
-        float *sv = p.save + r * (5 * D) + tid;
+        float *sv = p.save + r * (nsave * D) + tid;
         sv[0] = r_keep; sv[D] = u; sv[2 * D] = c; sv[3 * D] = T; sv[4 * D] = h;
+        if (seqrec) sv[5 * D] = N;
       }
     }
     __syncthreads();
@@ -169,7 +184,7 @@ struct BwdArgs {
   const float *d_short, *d_hs, *x, *timelast;
   const int32_t *seq_len;
   const float *wh_g, *wh_c, *tvec, *save;
-  int B, L;
+  int B, L, ldx;
   float *d_xproj, *rh, *d_xt, *d_tvec_partial;
 };
 
@@ -202,7 +217,9 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
     wgT[4 * q] = f32x2{v0.x, v1.x}; wgT[4 * q + 1] = f32x2{v0.y, v1.y};
     wgT[4 * q + 2] = f32x2{v0.z, v1.z}; wgT[4 * q + 3] = f32x2{v0.w, v1.w};
   }
-  const bool plain = p.tvec == nullptr;       // plain GRUCell: T = 1, no time-gate gradients
+  const bool seqrec = p.ldx == 5 * D;         // T-SeqRec cell: both time gates come hoisted in xproj
+  const bool plain = p.tvec == nullptr;       // plain GRUCell (T = 1) or T-SeqRec: no in-loop time-gate parameters
+  const int ldx = p.ldx, nsave = seqrec ? 6 : 5;
   float tv[NTV], gtv[NTV];
 #pragma unroll
   for (int i = 0; i < NTV; ++i) {
@@ -213,7 +230,7 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
   // zero-fill the dead steps of the outputs
   for (int t = steps; t < p.L; ++t) {
     const size_t r = row0 + t;
-    if (tid < 3 * D) p.d_xproj[r * (3 * D) + tid] = 0.f;
+    for (int c = tid; c < ldx; c += 512) p.d_xproj[r * ldx + c] = 0.f;
     if (tid < D) {
       p.rh[r * D + tid] = 0.f;
       p.d_xt[r * D + tid] = 0.f;
@@ -222,12 +239,13 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
 
   float dh = (tid < D && steps > 0) ? p.d_short[(size_t)b * D + tid] : 0.f;
 
-  float n_r = 0.f, n_u = 0.f, n_c = 0.f, n_T = 0.f, n_hp = 0.f, n_x = 0.f, n_dl = 0.f, n_dhs = 0.f;
+  float n_r = 0.f, n_u = 0.f, n_c = 0.f, n_T = 0.f, n_hp = 0.f, n_x = 0.f, n_dl = 0.f, n_dhs = 0.f, n_N = 1.f;
   auto prefetch = [&](int t) {
     if (tid < D) {
       const size_t r = row0 + t;
-      const float *sv = p.save + r * (5 * D) + tid;
+      const float *sv = p.save + r * (nsave * D) + tid;
       n_r = sv[0]; n_u = sv[D]; n_c = sv[2 * D]; n_T = sv[3 * D]; n_hp = sv[4 * D];
+      if (seqrec) n_N = sv[5 * D];
       n_x = p.x[r * D + tid];
       n_dl = p.timelast[r];
       if (p.d_hs) n_dhs = p.d_hs[r * D + tid];      // gradient on the step's OUTPUT (decoder keys = GRU outputs)
@@ -236,16 +254,21 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
   if (steps > 0) prefetch(steps - 1);
 
   for (int t = steps - 1; t >= 0; --t) {
-    const float r_ = n_r, u = n_u, c = n_c, T = n_T, hp = n_hp, xt = n_x, dl = n_dl;
+    const float r_ = n_r, u = n_u, c = n_c, T = n_T, hp = n_hp, xt = n_x, dl = n_dl, N = n_N;
     dh += n_dhs;
     if (t > 0) prefetch(t - 1);
     const size_t row = row0 + t;
     float du = 0.f, dhp = 0.f, dcpre = 0.f;
     if (tid < D) {
-      du = dh * (hp - c * T);
+      du = dh * (hp * N - c * T);
       const float dc = dh * (1.f - u) * T;
       const float dT = dh * (1.f - u) * c;
-      dhp = dh * u;
+      dhp = dh * u * N;
+      if (seqrec) {       // gradients of the two hoisted gate pre-activations
+        float *dx = p.d_xproj + row * ldx + tid;
+        dx[3 * D] = dh * u * hp * N * (1.f - N);
+        dx[4 * D] = dT * T * (1.f - T);
+      }
       dcpre = dc * (1.f - c * c);
       dc_s[tid] = dcpre;
       // time gate T = sigmoid(kw2*tw + w12*ts + b12), tw = relu(x*kw1 + kb1 + h*hw1), ts = relu(w1*dl + b1)
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
       const float dgu = du * u * (1.f - u);
       dg_s[tid] = dgr;
       dg_s[D + tid] = dgu;
-      float *dx = p.d_xproj + row * (3 * D) + tid;
+      float *dx = p.d_xproj + row * ldx + tid;
       dx[0] = dgr; dx[D] = dgu; dx[2 * D] = dcpre;
       p.rh[row * D + tid] = r_ * hp;
     }
@@ -332,7 +355,7 @@ extern "C" int mtam_tagru_fwd(const float *xproj, const float *x, const float *t
   MTAM_CHECK_ARG(B > 0 && L > 0, "tagru_fwd: B and L must be positive");
   MTAM_CHECK_ARG(xproj && x && timelast && seq_len && wh_g && wh_c && hs && short_out,
                  "tagru_fwd: null argument");        // tvec may be NULL: plain GRUCell
-  FwdArgs a{xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save};
+  FwdArgs a{xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, 3 * D, hs, short_out, save};
   hipLaunchKernelGGL(tagru_fwd_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("tagru_fwd");
   return MTAM_OK;
@@ -347,8 +370,89 @@ extern "C" int mtam_tagru_bwd(const float *d_short, const float *d_hs, const flo
                      d_tvec_partial,
                  "tagru_bwd: null argument");        // tvec (plain GRUCell) and d_hs may be NULL
   MTAM_CHECK_ARG(mtam_aligned16(wh_g) && mtam_aligned16(wh_c), "tagru_bwd: weights must be 16-byte aligned");
-  BwdArgs a{d_short, d_hs, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xproj, rh, d_xt, d_tvec_partial};
+  BwdArgs a{d_short, d_hs, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, 3 * D, d_xproj, rh, d_xt,
+            d_tvec_partial};
   hipLaunchKernelGGL(tagru_bwd_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("tagru_bwd");
+  return MTAM_OK;
+}
+
+// ---- T-SeqRec cell (TimeAwareGRUCell_sigmoid): the recurrence above with the two gates read from
+// columns 3 D .. 5 D of xproj [B*L, 5 D]; save [B*L, 6 D]; d_xproj [B*L, 5 D].
+extern "C" int mtam_tagru_seqrec_fwd(const float *xproj5, const int32_t *seq_len, const float *wh_g,
+                                     const float *wh_c, int B, int L, float *hs, float *short_out, float *save6,
+                                     void *stream) {
+  MTAM_CHECK_ARG(B > 0 && L > 0, "tagru_seqrec_fwd: B and L must be positive");
+  MTAM_CHECK_ARG(xproj5 && seq_len && wh_g && wh_c && hs && short_out, "tagru_seqrec_fwd: null argument");
+  FwdArgs a{xproj5, xproj5, xproj5, seq_len, wh_g, wh_c, nullptr, B, L, 5 * D, hs, short_out, save6};
+  hipLaunchKernelGGL(tagru_fwd_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), a);
+  MTAM_CHECK_LAUNCH("tagru_seqrec_fwd");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_tagru_seqrec_bwd(const float *d_short, const float *d_hs, const int32_t *seq_len,
+                                     const float *wh_g, const float *wh_c, const float *save6, int B, int L,
+                                     float *d_xproj5, float *rh, float *d_xt, float *d_tvec_partial, void *stream) {
+  MTAM_CHECK_ARG(B > 0 && L > 0, "tagru_seqrec_bwd: B and L must be positive");
+  MTAM_CHECK_ARG(d_short && seq_len && wh_g && wh_c && save6 && d_xproj5 && rh && d_xt && d_tvec_partial,
+                 "tagru_seqrec_bwd: null argument");
+  MTAM_CHECK_ARG(mtam_aligned16(wh_g) && mtam_aligned16(wh_c), "tagru_seqrec_bwd: weights must be 16-byte aligned");
+  // x / timelast are only read (their values unused) in this mode: any readable [B*L, D] / [B*L] buffer does
+  BwdArgs a{d_short, d_hs, save6, save6, seq_len, wh_g, wh_c, nullptr, save6, B, L, 5 * D, d_xproj5, rh, d_xt,
+            d_tvec_partial};
+  hipLaunchKernelGGL(tagru_bwd_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), a);
+  MTAM_CHECK_LAUNCH("tagru_seqrec_bwd");
+  return MTAM_OK;
+}
+
+// ---- the cell's time inputs: tin[r, 0:D] = tanh(timenow[r] w1 + b1), tin[r, D:2D] = tanh(timelast[r] w2 + b2)
+// (tvec4 rows: w1, b1, w2, b2), and their gradient products whose column sums are d(w1, b1, w2, b2):
+// out[r] = (g_now timenow[r] | g_now | g_last timelast[r] | g_last), g = d_tin (1 - tin^2).
+namespace {
+__global__ __launch_bounds__(256) void tsr_time_fwd_kernel(const float *__restrict__ timenow,
+                                                           const float *__restrict__ timelast,
+                                                           const float *__restrict__ tvec4, int R,
+                                                           float *__restrict__ tin) {
+  const int c = threadIdx.x;                 // 0 .. 2 D - 1
+  const bool last = c >= D;
+  const float wv = tvec4[(last ? 2 : 0) * D + (c & (D - 1))], bv = tvec4[(last ? 3 : 1) * D + (c & (D - 1))];
+  for (int r = blockIdx.x; r < R; r += gridDim.x) {
+    const float t = last ? timelast[r] : timenow[r];
+    tin[(size_t)r * (2 * D) + c] = tanhf(t * wv + bv);
+  }
+}
+__global__ __launch_bounds__(256) void tsr_time_bwd_kernel(const float *__restrict__ d_tin,
+                                                           const float *__restrict__ tin,
+                                                           const float *__restrict__ timenow,
+                                                           const float *__restrict__ timelast, int R,
+                                                           float *__restrict__ out) {
+  const int c = threadIdx.x;
+  const bool last = c >= D;
+  for (int r = blockIdx.x; r < R; r += gridDim.x) {
+    const float a = tin[(size_t)r * (2 * D) + c];
+    const float g = d_tin[(size_t)r * (2 * D) + c] * (1.f - a * a);
+    const float t = last ? timelast[r] : timenow[r];
+    float *o = out + (size_t)r * (4 * D) + (last ? 2 * D : 0) + (c & (D - 1));
+    o[0] = g * t;
+    o[D] = g;
+  }
+}
+}  // namespace
+
+extern "C" int mtam_tsr_time_inputs_fwd(const float *timenow, const float *timelast, const float *tvec4, int R,
+                                        float *tin, void *stream) {
+  MTAM_CHECK_ARG(timenow && timelast && tvec4 && tin && R > 0, "tsr_time_inputs_fwd: bad arguments");
+  hipLaunchKernelGGL(tsr_time_fwd_kernel, dim3(min(R, 2048)), dim3(2 * D), 0, static_cast<hipStream_t>(stream),
+                     timenow, timelast, tvec4, R, tin);
+  MTAM_CHECK_LAUNCH("tsr_time_inputs_fwd");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_tsr_time_inputs_bwd(const float *d_tin, const float *tin, const float *timenow,
+                                        const float *timelast, int R, float *out, void *stream) {
+  MTAM_CHECK_ARG(d_tin && tin && timenow && timelast && out && R > 0, "tsr_time_inputs_bwd: bad arguments");
+  hipLaunchKernelGGL(tsr_time_bwd_kernel, dim3(min(R, 2048)), dim3(2 * D), 0, static_cast<hipStream_t>(stream),
+                     d_tin, tin, timenow, timelast, R, out);
+  MTAM_CHECK_LAUNCH("tsr_time_inputs_bwd");
   return MTAM_OK;
 }

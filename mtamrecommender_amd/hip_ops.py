@@ -144,6 +144,31 @@ def tagru_bwd(d_short, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xpr
     _lib.check(rc, "mtam_tagru_bwd")
 
 
+def tagru_seqrec_fwd(xproj5, seq_len, wh_g, wh_c, B, L, hs, short_out, save6=None):
+    lib = _lib.load()
+    _lib.check(lib.mtam_tagru_seqrec_fwd(_p(xproj5), _pi(seq_len), _p(wh_g), _p(wh_c), B, L, _p(hs), _p(short_out),
+                                         _p(save6), _stream()), "mtam_tagru_seqrec_fwd")
+
+
+def tagru_seqrec_bwd(d_short, seq_len, wh_g, wh_c, save6, B, L, d_xproj5, rh, d_xt, d_tvec_partial, d_hs=None):
+    lib = _lib.load()
+    _lib.check(lib.mtam_tagru_seqrec_bwd(_p(d_short), _p(d_hs), _pi(seq_len), _p(wh_g), _p(wh_c), _p(save6), B, L,
+                                         _p(d_xproj5), _p(rh), _p(d_xt), _p(d_tvec_partial), _stream()),
+               "mtam_tagru_seqrec_bwd")
+
+
+def tsr_time_inputs_fwd(timenow, timelast, tvec4, R, tin):
+    lib = _lib.load()
+    _lib.check(lib.mtam_tsr_time_inputs_fwd(_p(timenow), _p(timelast), _p(tvec4), R, _p(tin), _stream()),
+               "mtam_tsr_time_inputs_fwd")
+
+
+def tsr_time_inputs_bwd(d_tin, tin, timenow, timelast, R, out):
+    lib = _lib.load()
+    _lib.check(lib.mtam_tsr_time_inputs_bwd(_p(d_tin), _p(tin), _p(timenow), _p(timelast), R, _p(out), _stream()),
+               "mtam_tsr_time_inputs_bwd")
+
+
 def ta_attn_decode_save_floats(L, H):
     return _lib.load().mtam_ta_attn_decode_save_floats(L, H)
 

@@ -345,7 +345,7 @@ def test_tf_named_npz_round_trip(hip_lib, tmp_path):
 
 
 @pytest.mark.parametrize("member", ["MTAM_only_time_aware_RNN", "MTAM_no_time_aware_rnn", "MTAM_via_T_GRU",
-                                    "MTAM_via_rnn"])
+                                    "MTAM_via_rnn", "MTAM_with_T_SeqRec"])
 @pytest.mark.parametrize("B,L,NB,H", [(6, 8, 1, 1), (33, 50, 2, 2)])
 def test_mtam_family_forward_and_gradients(hip_lib, tmp_path, member, B, L, NB, H):
     """The ablation members of Model/MTAMRec_model.py:40-238 that run on the MTAM kernels: logits, loss,

@@ -167,7 +167,8 @@ def test_padded_slots_have_exactly_zero_upstream_gradient():
         assert np.any(gi[b, sl - 1] != 0)             # the mask-token slot is an attention key
 
 
-FAMILY = ["MTAM", "MTAM_only_time_aware_RNN", "MTAM_no_time_aware_rnn", "MTAM_via_T_GRU", "MTAM_via_rnn"]
+FAMILY = ["MTAM", "MTAM_only_time_aware_RNN", "MTAM_no_time_aware_rnn", "MTAM_via_T_GRU", "MTAM_via_rnn",
+          "MTAM_with_T_SeqRec"]
 
 
 @pytest.mark.parametrize("model", FAMILY)
@@ -331,3 +332,28 @@ def test_family_members_differ_where_the_reference_says():
     short = O.gather_indexes(o3["hs"], f3["seq_length"] - 2)
     want = O.layer_norm(short, w3["ShortTermIntentEncoder/LayerNorm/beta"], w3["ShortTermIntentEncoder/LayerNorm/gamma"])
     assert np.abs(o3["pred"].numpy() - want.numpy()).max() < 1e-14
+
+
+def test_seqrec_cell_known_answer():
+    """TimeAwareGRUCell_sigmoid by hand (Model/Modules/time_aware_rnn.py:113-130): with every kernel zero the
+    gates are sigmoid(bias): r = u = sigmoid(0) = 1/2, c = tanh(atanh(1/2)) = 1/2, sigmoid(now) = sigmoid(ln 3)
+    = 3/4, sigmoid(last) = sigmoid(0) = 1/2:  h1 = (1-u) c s_last = 1/8,  h2 = u h1 s_now + 1/8 = 11/64; the
+    third step is past the sequence length: output 0, state kept."""
+    from mtamrecommender_amd.Model.variables import TSR_SCOPE, mtam_dense_specs
+    D = 4
+    w = {s.name: torch.zeros(s.shape, dtype=torch.float64) for s in mtam_dense_specs(D, 3, 1, "MTAM_with_T_SeqRec")
+         if s.name.startswith(TSR_SCOPE)}
+    w[TSR_SCOPE + "candidate/bias"] += float(np.arctanh(0.5))
+    w[TSR_SCOPE + "_time_bias1"] += float(np.log(3.0))
+    x = torch.ones((1, 3, D), dtype=torch.float64)
+    t = torch.tensor([[5.0, 7.0, 9.0]], dtype=torch.float64)
+    hs = O.seqrec_gru(w, x, t, t, torch.tensor([2]))
+    assert torch.allclose(hs[0, 0], torch.full((D,), 1 / 8, dtype=torch.float64), atol=1e-15)
+    assert torch.allclose(hs[0, 1], torch.full((D,), 11 / 64, dtype=torch.float64), atol=1e-15)
+    assert torch.equal(hs[0, 2], torch.zeros(D, dtype=torch.float64))
+    # the time inputs reach the state only through their [D, D] kernels: tanh(t w + b) with w = b = 0 is 0
+    w[TSR_SCOPE + "_time_kernel_t2"] += 1.0
+    w[TSR_SCOPE + "_time_input_bias2"] += float(np.arctanh(0.25))
+    hs2 = O.seqrec_gru(w, x, t, t, torch.tensor([2]))
+    s_last = 1.0 / (1.0 + np.exp(-D * 0.25))                 # last = sum_d tanh(b2) * 1 = D / 4
+    assert torch.allclose(hs2[0, 0], torch.full((D,), 0.25 * s_last, dtype=torch.float64), atol=1e-15)
