@@ -98,3 +98,10 @@ class MTAM_with_T_SeqRec(MTAM):
     """Model/MTAMRec_model.py:275-306: MTAM with the T-SeqRec cell (TimeAwareGRUCell_sigmoid) as the
     short-term encoder."""
     VARIANT = "MTAM_with_T_SeqRec"
+
+
+class MTAM_hybird(MTAM):
+    """Model/MTAMRec_model.py:240-273 (sic): MTAM whose scoring vector is
+    concat(short-term intent, layer_norm(decoder output)) . output_w (base_model.output_concat,
+    Model/base_model.py:329-357).  The reference imports it in train_process.py:26-27 and never dispatches it."""
+    VARIANT = "MTAM_hybird"

@@ -63,6 +63,8 @@ class DenseLayout(object):
                          ("blk%d/wt" % i, (D, D)), ("blk%d/tparams" % i, (5, L, L)),
                          ("blk%d/ln" % i, (2, D))]
         segs.append(("head/ln", (2, D)))
+        if self.mtam and self.cfg.get("head") == "concat":
+            segs.append(("head/output_w", (2 * D, D)))
         self.segments = collections.OrderedDict()
         off = 0
         for name, shape in segs:
@@ -136,6 +138,8 @@ class DenseLayout(object):
                 put("blk%d/tparams" % i, np.stack([tf_vars[a + n] for n in TIME_GATE]))
                 put("blk%d/ln" % i, np.stack([tf_vars[a + "ln/Variable"], tf_vars[a + "ln/Variable_1"]]))
         put("head/ln", np.stack([tf_vars[head + "beta"], tf_vars[head + "gamma"]]))
+        if "head/output_w" in self.segments:
+            put("head/output_w", tf_vars["output_w"])
         return flat
 
     def unpack(self, flat):
@@ -196,6 +200,8 @@ class DenseLayout(object):
                 out[a + "ln/Variable"], out[a + "ln/Variable_1"] = ln[0], ln[1]
         hl = get("head/ln")
         out[head + "beta"], out[head + "gamma"] = hl[0], hl[1]
+        if "head/output_w" in self.segments:
+            out["output_w"] = get("head/output_w")
         return out
 
     def dead_names(self):

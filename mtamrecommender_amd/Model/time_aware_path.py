@@ -92,6 +92,10 @@ class _Batch(object):
         self.dec = [self.short_n if path.cfg["short_ln"] else self.short] + [f(B, D) for _ in range(NB)]
         self.attn_save = [f(B, ops.ta_attn_decode_save_floats(L, H)) for _ in range(NB)]
         self.pred, self.ln_save = f(B, D), f(B, D + 1)
+        # pred = what the catalog is scored with; ln_out = the head layer_norm's output.  The same buffer,
+        # except under the output_concat head (MTAM_hybird), where pred = [short | ln_out] . output_w
+        self.concat_head = path.cfg.get("head") == "concat"
+        self.ln_out = f(B, D) if self.concat_head else self.pred
         # logits rows start on 16-byte boundaries (row stride = V rounded up to 4 floats) so that the
         # transposed read of d_logits in the item-gradient GEMM takes the vector-load path; `logits` is the
         # [B, V] view of that storage
@@ -119,6 +123,7 @@ class _Batch(object):
         # to the GRU outputs (d_hs) and d_x only receives the GRU's input-path gradient
         self.d_clear = f(B * D + R * D)
         self.d_pred = self.d_clear[:B * D].view(B, D)
+        self.d_ln_out = f(B, D) if self.concat_head else self.d_pred
         if path.cfg["keys"] == "gru":
             self.d_x = self.d_clear[B * D:].view(R, D)
             self.d_hs = f(R, D)
@@ -326,14 +331,17 @@ class TimeAwarePath(object):
             for i in range(NB):
                 ln = self.seg("blk%d/ln" % i)
                 # the last block also applies the head layer_norm (pred) in the same launch
-                head = (hl[0], hl[1], bt.pred, bt.ln_save if training else None) if i == NB - 1 else None
+                head = (hl[0], hl[1], bt.ln_out, bt.ln_save if training else None) if i == NB - 1 else None
                 ops.ta_attn_decode_fwd(bt.dec[i], keys, bt.kv, 2 * NB * D, 2 * i * D, (2 * i + 1) * D,
                                        fd["target_item_time"], fd["time_list"], fd["seq_length"],
                                        self.seg("blk%d/wqt" % i), self.seg("blk%d/bq" % i),
                                        self.seg("blk%d/tparams" % i), ln[0], ln[1], B, L, H, bt.dec[i + 1],
                                        bt.attn_save[i] if training else None, head=head)
         else:
-            ops.layer_norm_fwd(bt.short, hl[0], hl[1], 1e-12, B, bt.pred, bt.ln_save if training else None)
+            ops.layer_norm_fwd(bt.short, hl[0], hl[1], 1e-12, B, bt.ln_out, bt.ln_save if training else None)
+        if bt.concat_head:
+            W = self.seg("head/output_w")
+            ops.gemm_dual(bt.short, W[:D], bt.ln_out, W[D:], bt.pred, trans_b=False)
         self.score_forward(bt, training)
 
     def loss_and_logit_grad(self, bt):
@@ -357,6 +365,9 @@ class TimeAwarePath(object):
         prob = lambda A, lda, Bm, ldb, name, M, N, K, s: dict(A=A, lda=lda, B=Bm, ldb=ldb, C=gseg(name),
                                                               ldc=N, M=M, N=N, K=K, split_k=s)
         self.score_backward(bt)          # d_pred -> head LN -> decoder blocks (last to first)
+        if bt.concat_head:               # back through output_w: d(ln_out) now, d(short) after the decoder
+            W = self.seg("head/output_w")
+            ops.gemm(bt.d_pred, W[D:], bt.d_ln_out, trans_b=True)
         keys = bt.hs if cfg["keys"] == "gru" else bt.x
         d_keys = bt.d_hs if cfg["keys"] == "gru" else bt.d_x      # gradient of user_history
         problems, jobs = [], []
@@ -364,7 +375,7 @@ class TimeAwarePath(object):
             for i in reversed(range(NB)):
                 ln = self.seg("blk%d/ln" % i)
                 # the last block starts from d_pred: backward of the fused head layer_norm
-                head = (bt.d_pred, self.seg("head/ln")[1], bt.ln_save, bt.d_head_partial) if i == NB - 1 else None
+                head = (bt.d_ln_out, self.seg("head/ln")[1], bt.ln_save, bt.d_head_partial) if i == NB - 1 else None
                 ops.ta_attn_decode_bwd(None if head else bt.d_dec[i + 1], bt.dec[i], keys, bt.kv, 2 * NB * D,
                                        2 * i * D, (2 * i + 1) * D, fd["target_item_time"], fd["time_list"],
                                        fd["seq_length"], self.seg("blk%d/wqt" % i), self.seg("blk%d/tparams" % i),
@@ -385,8 +396,13 @@ class TimeAwarePath(object):
                 ops.gemm(bt.d_kv, self.seg("kv/w"), d_keys, trans_b=True, epilogue=ops.EPI_ACCUM)
             d_short = bt.d_dec[0]
         else:
-            ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_short, gseg("head/ln"))
+            ops.layer_norm_bwd(bt.d_ln_out, self.seg("head/ln")[1], bt.ln_save, B, bt.d_short, gseg("head/ln"))
             d_short = bt.d_short
+        if bt.concat_head:
+            W, gW = self.seg("head/output_w"), gseg("head/output_w")
+            ops.gemm(bt.d_pred, W[:D], d_short, trans_b=True, epilogue=ops.EPI_ACCUM)
+            problems += [dict(A=bt.short, lda=D, B=bt.d_pred, ldb=D, C=gW[:D], ldc=D, M=D, N=D, K=B, split_k=1),
+                         dict(A=bt.ln_out, lda=D, B=bt.d_pred, ldb=D, C=gW[D:], ldc=D, M=D, N=D, K=B, split_k=1)]
         if cfg["short_ln"]:
             ops.layer_norm_bwd(d_short, self.seg("short/ln")[1], bt.short_ln_save, B, bt.d_short, gseg("short/ln"))
             d_short = bt.d_short

@@ -27,8 +27,9 @@ SHORT_LN = "ShortTermIntentEncoder/LayerNorm/"
 
 # The MTAM family (Model/MTAMRec_model.py:40-306): which recurrent cell encodes the short-term intent,
 # what the decoder attends over, and where layer norms sit.  The three members that need other
-# kernels are not built: MTAM_no_time_aware_att (non-time-aware attention with live dropout,
-# SURVEY.md F8) and MTAM_hybird (output_concat head; never dispatched by train_process.py).
+# kernels is not built: MTAM_no_time_aware_att (non-time-aware attention with live dropout).
+# head="concat" (MTAM_hybird): predict = concat(short-term intent, layer_norm(decoder)) . output_w before the
+# catalog product (base_model.output_concat, Model/base_model.py:329-357).
 MTAM_VARIANTS = {
     # name: (gru cell, attention keys, layer_norm on the short-term intent, attention decoder)
     "MTAM": dict(gru="time", keys="x", short_ln=False, attention=True),                       # :61-92
@@ -37,6 +38,7 @@ MTAM_VARIANTS = {
     "MTAM_via_T_GRU": dict(gru="time", keys="gru", short_ln=True, attention=True),             # :167-204
     "MTAM_via_rnn": dict(gru="plain", keys="gru", short_ln=True, attention=True),              # :206-238
     "MTAM_with_T_SeqRec": dict(gru="seqrec", keys="x", short_ln=False, attention=True),        # :275-306
+    "MTAM_hybird": dict(gru="time", keys="x", short_ln=False, attention=True, head="concat"),  # :240-273
 }
 
 
@@ -124,6 +126,8 @@ def mtam_dense_specs(D, L, num_blocks, variant="MTAM"):
     head = head_ln_scope(variant)
     specs.append(VarSpec(head + "beta", (D,), ("const", 0.0), True))
     specs.append(VarSpec(head + "gamma", (D,), ("const", 1.0), True))
+    if cfg.get("head") == "concat":
+        specs.append(VarSpec("output_w", (2 * D, D), _glorot((2 * D, D)), True))       # base_model.py:340-342
     return specs
 
 

@@ -103,7 +103,8 @@ class Train_main_process(object):
         members = {"MTAM": family.MTAM, "T_GRU": family.MTAM_only_time_aware_RNN,
                    "MTAM_no_time_aware_rnn": family.MTAM_no_time_aware_rnn,
                    "MTAM_via_T_GRU": family.MTAM_via_T_GRU, "MTAM_via_rnn": family.MTAM_via_rnn,
-                   "MTAM_with_T_SeqRec": family.MTAM_with_T_SeqRec}          # train_process.py:217-218
+                   "MTAM_with_T_SeqRec": family.MTAM_with_T_SeqRec,          # train_process.py:217-218
+                   "MTAM_hybird": family.MTAM_hybird}      # imported by the reference's trainer, reachable only here
         if self.FLAGS.experiment_type in members:
             self.model = members[self.FLAGS.experiment_type](self.FLAGS, self.emb, self.sess)
         elif self.FLAGS.experiment_type in ("Time_Aware_Self_Attention_Model", "PISTRec"):

@@ -247,6 +247,9 @@ def forward(model, w, feed, num_heads, num_blocks, regulation_rate, global_batch
                                      num_blocks)
         head = head_ln_scope(model)
         pred = layer_norm(last, w[head + "beta"], w[head + "gamma"])
+        if cfg.get("head") == "concat":
+            # MTAM_hybird (Model/MTAMRec_model.py:272) + base_model.output_concat (Model/base_model.py:340-346)
+            pred = torch.matmul(torch.cat([short, pred], 1), w["output_w"])
         l2 = 0.5 * (item ** 2).sum() + 0.5 * (cat ** 2).sum() + 0.5 * (pos ** 2).sum() \
             + 0.5 * (user ** 2).sum()
     else:

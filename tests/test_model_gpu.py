@@ -345,7 +345,7 @@ def test_tf_named_npz_round_trip(hip_lib, tmp_path):
 
 
 @pytest.mark.parametrize("member", ["MTAM_only_time_aware_RNN", "MTAM_no_time_aware_rnn", "MTAM_via_T_GRU",
-                                    "MTAM_via_rnn", "MTAM_with_T_SeqRec"])
+                                    "MTAM_via_rnn", "MTAM_with_T_SeqRec", "MTAM_hybird"])
 @pytest.mark.parametrize("B,L,NB,H", [(6, 8, 1, 1), (33, 50, 2, 2)])
 def test_mtam_family_forward_and_gradients(hip_lib, tmp_path, member, B, L, NB, H):
     """The ablation members of Model/MTAMRec_model.py:40-238 that run on the MTAM kernels: logits, loss,
@@ -376,15 +376,16 @@ def test_mtam_family_forward_and_gradients(hip_lib, tmp_path, member, B, L, NB, 
     assert abs(float(p.scale[1]) - ref_norm) / ref_norm < 1e-4
 
 
-def test_mtam_family_trains_through_the_graph(hip_lib, tmp_path):
+@pytest.mark.parametrize("member", ["MTAM_via_T_GRU", "MTAM_with_T_SeqRec"])
+def test_mtam_family_trains_through_the_graph(hip_lib, tmp_path, member):
     import oracle.mtam_oracle as O
     B, L, NB, H = 16, 20, 1, 1
-    model, FLAGS, records = build(tmp_path, B, L, NB, H, model_name="MTAM_via_T_GRU")
+    model, FLAGS, records = build(tmp_path, B, L, NB, H, model_name=member)
     arrays = {k: v.copy() for k, v in model.get_variables().items()}
     state = O.AdamState(arrays)
     for step in range(4):                                   # step 3+ replays the captured hipGraph
         feed = model.embedding.make_feed_dic_new(records)
-        ref = O.train_step("MTAM_via_T_GRU", arrays, state, feed, 1e-3, H, NB, FLAGS.regulation_rate,
+        ref = O.train_step(member, arrays, state, feed, 1e-3, H, NB, FLAGS.regulation_rate,
                            FLAGS.max_gradient_norm, True)
         loss, _ = model.train(model.sess, records, 1e-3)
         assert abs(loss - ref["loss"]) / abs(ref["loss"]) < 1e-4, step

@@ -77,7 +77,7 @@ def test_pack_matches_make_feed_dic_new(host):
     packed = packer.pack(rs, idx, lr=0.125)
     feed = emb.make_feed_dic_new([records[i] for i in idx])
     for name in ("user_id", "item_list", "category_list", "position_list", "target_item_id", "seq_length",
-                 "time_list", "timelast_list", "target_item_time"):
+                 "time_list", "timelast_list", "timenow_list", "target_item_time"):
         assert np.array_equal(packed.field(name), feed[name]), name
     assert packed.field("lr")[0] == np.float32(0.125)
     assert len(packed) == 6 and packed.records()[2] == rs.record(36)

@@ -168,7 +168,7 @@ def test_padded_slots_have_exactly_zero_upstream_gradient():
 
 
 FAMILY = ["MTAM", "MTAM_only_time_aware_RNN", "MTAM_no_time_aware_rnn", "MTAM_via_T_GRU", "MTAM_via_rnn",
-          "MTAM_with_T_SeqRec"]
+          "MTAM_with_T_SeqRec", "MTAM_hybird"]
 
 
 @pytest.mark.parametrize("model", FAMILY)
