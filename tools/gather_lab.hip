@@ -34,13 +34,13 @@ __global__ __launch_bounds__(256) void k_ids_only(Args p) {
 }
 
 // SLOTS rows in flight per half wave; NT: non-temporal stores; SCALAR: ids through readfirstlane
-template <int SLOTS, bool NT, bool SCALAR>
-__global__ __launch_bounds__(256) void k_gather(Args p) {
+template <int SLOTS, bool NT, bool SCALAR, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void k_gather(Args p) {
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, li = lane & 31;
   const int R = p.B * p.L;
   const int total = R + (R + p.B + 1) / 2;
-  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave_id = blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
   const int s0 = wave_id * SLOTS;
   const float *src[SLOTS];
   float *dst[SLOTS];
@@ -153,6 +153,22 @@ int main(int argc, char **argv) {
   report("ids_only", time_graph([&] { hipLaunchKernelGGL(k_ids_only, dim3(blocks(4)), dim3(256), 0, st, a); }, st));
 #define RUN(S, NT, SC) report("gather slots=" #S " nt=" #NT " scalar=" #SC, time_graph([&] { \
     hipLaunchKernelGGL((k_gather<S, NT, SC>), dim3(blocks(S)), dim3(256), 0, st, a); }, st))
+  // launch floor against the number (and size) of workgroups
+  for (int g : {128, 256, 604, 1208, 2416, 4832})
+    for (int th : {64, 256, 512, 1024}) {
+      char name[64];
+      snprintf(name, sizeof name, "empty grid=%d threads=%d", g, th);
+      report(name, time_graph([&] { hipLaunchKernelGGL(k_empty, dim3(g), dim3(th), 0, st, a); }, st));
+    }
+#define RUNT(S, TH) report("gather slots=" #S " threads=" #TH, time_graph([&] { \
+    hipLaunchKernelGGL((k_gather<S, false, false, TH>), dim3(((total + S - 1) / S + TH / 64 - 1) / (TH / 64)), dim3(TH), 0, st, a); }, st))
+  RUNT(2, 128);
+  RUNT(2, 512);
+  RUNT(2, 1024);
+  RUNT(1, 512);
+  RUNT(1, 1024);
+  RUNT(3, 256);
+  RUNT(3, 512);
   RUN(1, false, false);
   RUN(2, false, false);
   RUN(4, false, false);
