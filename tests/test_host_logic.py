@@ -57,9 +57,11 @@ def test_flags_defaults_and_presets():
     assert f.train_batch_size == 64 and f.num_heads == 2
 
 
-@pytest.mark.parametrize("model,specs_fn", [("MTAM", mtam_dense_specs), ("PISTRec", pistrec_dense_specs)])
+@pytest.mark.parametrize("model,specs_fn", [("MTAM", mtam_dense_specs), ("PISTRec", pistrec_dense_specs)] + [
+    (m, None) for m in ("MTAM_only_time_aware_RNN", "MTAM_no_time_aware_rnn", "MTAM_via_T_GRU", "MTAM_via_rnn",
+                        "MTAM_with_T_SeqRec", "MTAM_hybird")])
 def test_dense_layout_round_trip(model, specs_fn):
-    specs = specs_fn(128, 50, 3)
+    specs = specs_fn(128, 50, 3) if specs_fn else mtam_dense_specs(128, 50, 3, model)
     values = init_variables(specs, seed=1)
     live = {s.name: values[s.name] for s in specs if s.trainable_grad}
     lay = DenseLayout(model, 128, 50, 3)
