@@ -160,6 +160,17 @@ int mtam_emb_gather_fwd_clear(const float *item_table, int item_rows,
                               float *item_cat_out, float *pos_out, float *user_out,
                               float *l2_partial, float *clear_a, size_t n_a, float *clear_b, size_t n_b,
                               void *stream);
+/* The same launch with the ITEM rows read from a bf16 image of the item table (item16 [item_rows, 128] bf16
+ * bits, e.g. the scoring copy kept by mtam_adam_bf16copy) and widened to fp32: mixed-precision runs then
+ * read the item table in bf16 everywhere in the forward.  item16 == NULL: identical to the call above
+ * (item_table is still required: it is what a NULL item16 falls back to). */
+int mtam_emb_gather_fwd_item16(const float *item_table, const uint16_t *item16, int item_rows,
+                               const float *cat_table, int cat_rows, const float *pos_table, int pos_rows,
+                               const float *user_table, int user_rows, const int32_t *item_ids,
+                               const int32_t *cat_ids, const int32_t *pos_ids, const int32_t *user_ids, int B,
+                               int L, int with_user, float *item_cat_out, float *pos_out, float *user_out,
+                               float *l2_partial, float *clear_a, size_t n_a, float *clear_b, size_t n_b,
+                               void *stream);
 
 /* ---------------------------------------------------- embedding scatter-add
  * Gradient of the four lookups (tf.gradients through embedding_lookup,

@@ -58,7 +58,7 @@ class SelfAttentionPath(TimeAwarePath):
                            fd["category_list"], fd["position_list"], fd["user_id"], B, L, 0,
                            bt.ic, bt.pos, bt.user, bt.l2_partial,
                            # a training step's first kernel also clears its gradient accumulators
-                           clear=(self.zero_prefix, bt.d_pred.view(-1)) if training else ())
+                           clear=(self.zero_prefix, bt.d_pred.view(-1)) if training else (), item16=self.item16)
         ops.gemm(bt.ic, self.seg("dense4emb/w"), bt.x, epilogue=ops.EPI_RELU_ADD, aux_in=bt.pos, aux_out=bt.zr)
         for i in range(NB):
             enc, qkv, qt = bt.enc[i], bt.qkv[i], bt.qt[i]

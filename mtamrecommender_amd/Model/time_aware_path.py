@@ -158,9 +158,10 @@ class TimeAwarePath(object):
         self.optimizer = optimizer
         if score_dtype not in ("f32", "bf16"):
             raise ValueError("score_dtype must be 'f32' or 'bf16' (got %r)" % (score_dtype,))
-        # "bf16" (BASELINE.json configs[4]): full-catalog scoring from a bf16 copy of the item table with
-        # bf16 MFMA / fp32 accumulation and no stored logits (csrc/score16.hip); fp32 master weights,
-        # gradients and optimizer slots, fp32 sequence side -- the autocast form of mixed precision
+        # "bf16" (BASELINE.json configs[4]): the forward reads the item table from a bf16 copy -- history
+        # gathers widen its rows to fp32, full-catalog scoring runs on bf16 MFMA with fp32 accumulation and
+        # no stored logits (csrc/score16.hip); fp32 master weights, gradients and optimizer slots, fp32
+        # activations on the sequence side, fp32 atomics in the scatter-add
         self.score_dtype = score_dtype
         from .variables import MTAM_VARIANTS
         if variant is not None:
@@ -298,7 +299,7 @@ class TimeAwarePath(object):
                            bt.ic, bt.pos, bt.user, bt.l2_partial,
                            # a training step's first kernel also clears its gradient accumulators
                            clear=(self.zero_prefix, bt.d_clear if cfg["keys"] == "gru" else bt.d_pred.view(-1))
-                           if training else ())
+                           if training else (), item16=self.item16)
         ops.gemm(bt.ic, self.seg("dense4emb/w"), bt.x, epilogue=ops.EPI_RELU_ADD, aux_in=bt.pos, aux_out=bt.zr)
         keys = bt.hs if cfg["keys"] == "gru" else bt.x        # user_history: what the decoder attends over
         if cfg["attention"] and cfg["keys"] == "x":           # keys/values of every block (before the GRU)

@@ -32,6 +32,8 @@ SIGNATURES = {
                                     P, P, P, P, P]),
     "mtam_emb_gather_fwd_clear": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
                                           P, P, P, P, P, c_size_t, P, c_size_t, P]),
+    "mtam_emb_gather_fwd_item16": (c_int, [P, P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
+                                           P, P, P, P, P, c_size_t, P, c_size_t, P]),
     "mtam_emb_scatter_partials": (c_int, [c_int, c_int]),
     "mtam_emb_scatter_add_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
                                          P, c_int, P, c_int, P, c_int, P, c_int, P, P]),

@@ -30,10 +30,15 @@ struct GatherArgs {
   // The gather is the first kernel of a training step and is latency-bound, so the stores ride along.
   float4 *clear_a, *clear_b;
   size_t n_a4, n_b4;
+  const uint16_t *item16;      // ITEM16: the item rows are read from this bf16 image of the table (256 B per row)
 };
 
 // Slot s < R      : row r = s of the [item | category] concat, one wave (halves = item, category).
 // Slot s >= R     : two rows of {position rows 0..R-1, user rows R..R+B-1}, one per half wave.
+// ITEM16 (mixed precision, BASELINE.json configs[4]): item rows come from the bf16 copy and are widened to
+// fp32 on the way to the activations; a lane then needs 8 bytes of an item row or 16 of any other row, so
+// every lane issues two 8-byte loads (the second one redundant for item lanes) -- uniform, unconditional.
+template <bool ITEM16>
 __global__ __launch_bounds__(256) void emb_gather_kernel(GatherArgs p) {
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, li = lane & 31;
@@ -46,17 +51,23 @@ __global__ __launch_bounds__(256) void emb_gather_kernel(GatherArgs p) {
   const float *src[SLOTS_PER_WAVE];
   float *dst[SLOTS_PER_WAVE];
   bool count[SLOTS_PER_WAVE];
+  bool narrow[SLOTS_PER_WAVE];
 #pragma unroll
   for (int i = 0; i < SLOTS_PER_WAVE; ++i) {
     const int s = s0 + i;
     src[i] = nullptr;
     dst[i] = nullptr;
     count[i] = true;
+    narrow[i] = false;
     if (s < slots_ic) {
       const int id = half ? p.cat_ids[s] : p.item_ids[s];
       const float *tab = half ? p.cat_table : p.item_table;
       const int rows = half ? p.cat_rows : p.item_rows;
       src[i] = tab + (size_t)clamp_id(id, rows) * D + 4 * li;
+      if (ITEM16 && !half) {
+        src[i] = reinterpret_cast<const float *>(p.item16 + (size_t)clamp_id(id, rows) * D + 4 * li);
+        narrow[i] = true;
+      }
       dst[i] = p.ic_out + (size_t)s * (2 * D) + half * D + 4 * li;
     } else if (s < total) {
       const int q = 2 * (s - slots_ic) + half;
@@ -72,9 +83,29 @@ __global__ __launch_bounds__(256) void emb_gather_kernel(GatherArgs p) {
     }
   }
   float4 v[SLOTS_PER_WAVE];
+  if (ITEM16) {
+    uint2 lo[SLOTS_PER_WAVE], hi[SLOTS_PER_WAVE];
 #pragma unroll
-  for (int i = 0; i < SLOTS_PER_WAVE; ++i)
-    v[i] = src[i] ? *reinterpret_cast<const float4 *>(src[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < SLOTS_PER_WAVE; ++i) {
+      const uint2 *q = reinterpret_cast<const uint2 *>(src[i] ? src[i] : p.cat_table);
+      lo[i] = q[0];
+      hi[i] = q[narrow[i] ? 0 : 1];
+    }
+#pragma unroll
+    for (int i = 0; i < SLOTS_PER_WAVE; ++i) {
+      if (narrow[i])          // four bf16: element 0 in the low half of the first word
+        v[i] = make_float4(__uint_as_float(lo[i].x << 16), __uint_as_float(lo[i].x & 0xffff0000u),
+                           __uint_as_float(lo[i].y << 16), __uint_as_float(lo[i].y & 0xffff0000u));
+      else
+        v[i] = make_float4(__uint_as_float(lo[i].x), __uint_as_float(lo[i].y), __uint_as_float(hi[i].x),
+                           __uint_as_float(hi[i].y));
+      if (!src[i]) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SLOTS_PER_WAVE; ++i)
+      v[i] = src[i] ? *reinterpret_cast<const float4 *>(src[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < SLOTS_PER_WAVE; ++i) {
@@ -362,6 +393,19 @@ extern "C" int mtam_emb_gather_fwd_clear(const float *item_table, int item_rows,
                                          float *item_cat_out, float *pos_out, float *user_out,
                                          float *l2_partial, float *clear_a, size_t n_a, float *clear_b,
                                          size_t n_b, void *stream) {
+  return mtam_emb_gather_fwd_item16(item_table, nullptr, item_rows, cat_table, cat_rows, pos_table, pos_rows,
+                                    user_table, user_rows, item_ids, cat_ids, pos_ids, user_ids, B, L, with_user,
+                                    item_cat_out, pos_out, user_out, l2_partial, clear_a, n_a, clear_b, n_b, stream);
+}
+
+extern "C" int mtam_emb_gather_fwd_item16(const float *item_table, const uint16_t *item16, int item_rows,
+                                          const float *cat_table, int cat_rows, const float *pos_table,
+                                          int pos_rows, const float *user_table, int user_rows,
+                                          const int32_t *item_ids, const int32_t *cat_ids, const int32_t *pos_ids,
+                                          const int32_t *user_ids, int B, int L, int with_user,
+                                          float *item_cat_out, float *pos_out, float *user_out, float *l2_partial,
+                                          float *clear_a, size_t n_a, float *clear_b, size_t n_b, void *stream) {
+  MTAM_CHECK_ARG(!item16 || (reinterpret_cast<uintptr_t>(item16) & 7u) == 0, "emb_gather: item16 must be 8-byte aligned");
   MTAM_CHECK_ARG((n_a == 0 || (clear_a && mtam_aligned16(clear_a) && n_a % 4 == 0)) &&
                      (n_b == 0 || (clear_b && mtam_aligned16(clear_b) && n_b % 4 == 0)),
                  "emb_gather: clear ranges must be 16-byte aligned multiples of 4 floats");
@@ -378,9 +422,12 @@ extern "C" int mtam_emb_gather_fwd_clear(const float *item_table, int item_rows,
   GatherArgs a{item_table, cat_table, pos_table, user_table, item_rows, cat_rows, pos_rows, user_rows,
                item_ids, cat_ids, pos_ids, user_ids, B, L, with_user,
                item_cat_out, pos_out, user_out, l2_partial,
-               reinterpret_cast<float4 *>(clear_a), reinterpret_cast<float4 *>(clear_b), n_a / 4, n_b / 4};
+               reinterpret_cast<float4 *>(clear_a), reinterpret_cast<float4 *>(clear_b), n_a / 4, n_b / 4, item16};
   const int blocks = mtam_emb_gather_partials(B, L) / 4;
-  hipLaunchKernelGGL(emb_gather_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  if (item16)
+    hipLaunchKernelGGL(emb_gather_kernel<true>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(emb_gather_kernel<false>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("emb_gather");
   return MTAM_OK;
 }

@@ -100,17 +100,19 @@ def emb_gather_partials(B, L):
 
 
 def emb_gather_fwd(item_table, cat_table, pos_table, user_table, item_ids, cat_ids, pos_ids, user_ids,
-                   B, L, with_user, ic_out, pos_out, user_out, l2_partial, clear=()):
-    """clear: up to two flat float tensors zeroed by the same launch (the step's gradient accumulators)."""
+                   B, L, with_user, ic_out, pos_out, user_out, l2_partial, clear=(), item16=None):
+    """clear: up to two flat float tensors zeroed by the same launch (the step's gradient accumulators).
+    item16: bf16 image of the item table to read the item rows from (mixed precision)."""
     lib = _lib.load()
     ca = clear[0] if len(clear) > 0 else None
     cb = clear[1] if len(clear) > 1 else None
-    rc = lib.mtam_emb_gather_fwd_clear(_p(item_table), item_table.shape[0], _p(cat_table), cat_table.shape[0],
-                                       _p(pos_table), pos_table.shape[0], _p(user_table), user_table.shape[0],
-                                       _pi(item_ids), _pi(cat_ids), _pi(pos_ids), _pi(user_ids), B, L,
-                                       int(with_user), _p(ic_out), _p(pos_out), _p(user_out), _p(l2_partial),
-                                       _p(ca), ca.numel() if ca is not None else 0,
-                                       _p(cb), cb.numel() if cb is not None else 0, _stream())
+    rc = lib.mtam_emb_gather_fwd_item16(_p(item_table), _p(item16, torch.bfloat16) if item16 is not None else None,
+                                        item_table.shape[0], _p(cat_table), cat_table.shape[0],
+                                        _p(pos_table), pos_table.shape[0], _p(user_table), user_table.shape[0],
+                                        _pi(item_ids), _pi(cat_ids), _pi(pos_ids), _pi(user_ids), B, L,
+                                        int(with_user), _p(ic_out), _p(pos_out), _p(user_out), _p(l2_partial),
+                                        _p(ca), ca.numel() if ca is not None else 0,
+                                        _p(cb), cb.numel() if cb is not None else 0, _stream())
     _lib.check(rc, "mtam_emb_gather_fwd")
 
 

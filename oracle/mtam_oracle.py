@@ -44,10 +44,14 @@ def feed_to_torch(feed, dtype):
 
 
 # ---------------------------------------------------------------- embedding
-def get_embedding(w, feed):
-    """Embedding/Behavior_embedding_time_aware_attention.py:62-114."""
+def get_embedding(w, feed, item_dtype="f32"):
+    """Embedding/Behavior_embedding_time_aware_attention.py:62-114.  item_dtype "bf16" (this build's mixed
+    precision): the looked-up item rows are the bf16-rounded ones."""
     user = w["embedding_layer/user"][feed["user_id"]]
-    item = w["embedding_layer/item_gather"][feed["item_list"]]
+    item_table = w["embedding_layer/item_gather"]
+    if item_dtype == "bf16":
+        item_table = _bf16_straight_through(item_table)
+    item = item_table[feed["item_list"]]
     cat = w["embedding_layer/category"][feed["category_list"]]
     pos = w["embedding_layer/position"][feed["position_list"]]
     concat = torch.cat([item, cat], dim=2)
@@ -221,10 +225,11 @@ def forward(model, w, feed, num_heads, num_blocks, regulation_rate, global_batch
     the gather gradient and the dense scoring gradient stay separable, as TF's
     IndexedSlices aggregation keeps them.
     ``global_batch``: mean divisor for data-parallel shards (default: local B).
-    ``score_dtype`` "bf16" (an option of this build, BASELINE.json configs[4]; not in the reference): both
-    operands of the scoring product are rounded to bf16, products and sums stay in the working precision.
+    ``score_dtype`` "bf16" (an option of this build, BASELINE.json configs[4]; not in the reference): the
+    item table is read in bf16 everywhere in the forward (history gathers and scoring), the scoring vector is
+    rounded to bf16 in front of the catalog product; products and sums stay in the working precision.
     """
-    user, x, item, cat, pos = get_embedding(w, feed)
+    user, x, item, cat, pos = get_embedding(w, feed, score_dtype)
     sl = feed["seq_length"]
     B = x.shape[0]
     if model in MTAM_VARIANTS:

@@ -220,6 +220,8 @@ def test_c5_bf16_scoring_50m_items_l200(hip_lib, tmp_path):
     bt = p.load_feed(feed)
     p.eval_kernels(bt, 50)
     tgt = torch.from_numpy(feed["target_item_id"].astype(np.int64)).cuda()
+    hist = torch.from_numpy(feed["item_list"].astype(np.int64)).cuda().view(-1)
+    assert torch.equal(bt.ic[:, :128], p.item16[hist].float())       # history rows: the bf16 image, widened
     cols = torch.cat([torch.randint(0, V, (4096,), device="cuda"), tgt, torch.tensor([0, V - 1], device="cuda")])
     P16 = bt.pred.bfloat16().double()
     own = P16 @ p.item16[cols].double().T

@@ -813,3 +813,30 @@ def test_score16_lse_logits_and_backward(ops, B, V):
     # gradient rows of the softmax sum to ~0 over the catalog: dE^T 1 = pred^T (G 1) -- the bf16 rounding of G
     # leaves a residue well below one rounding step of the largest entry
     assert abs(float(sq.double().sum()) - float((dE.double() ** 2).sum())) < 1e-5 * float((dE.double() ** 2).sum())
+
+
+def test_gather_reads_item_rows_from_the_bf16_copy(ops):
+    """mtam_emb_gather_fwd_item16: item rows = the bf16 image widened to fp32 (bit-exact), every other output
+    identical to the fp32 call, the L2 partials are those of the values actually gathered."""
+    rng = np.random.default_rng(11)
+    B, L, V, NC, NP, NU = 37, 20, 500, 31, 23, 50
+    tabs = [rng.standard_normal((n, D)).astype(np.float32) for n in (V, NC, NP, NU)]
+    ids = [rng.integers(0, n, B * L).astype(np.int32) for n in (V, NC, NP)] + [rng.integers(0, NU, B).astype(np.int32)]
+    t = [dev(x) for x in tabs]
+    i = [dev(x) for x in ids]
+    item16 = torch.empty((V, D), dtype=torch.bfloat16, device="cuda")
+    ops.f32_to_bf16(t[0].view(-1), item16.view(-1))
+    outs = []
+    for use16 in (None, item16):
+        ic = torch.zeros((B * L, 2 * D), device="cuda")
+        pos = torch.zeros((B * L, D), device="cuda")
+        user = torch.zeros((B, D), device="cuda")
+        l2 = torch.zeros(ops.emb_gather_partials(B, L), device="cuda")
+        ops.emb_gather_fwd(t[0], t[1], t[2], t[3], i[0], i[1], i[2], i[3], B, L, 1, ic, pos, user, l2, item16=use16)
+        outs.append((ic, pos, user, l2))
+    (ic0, pos0, user0, l20), (ic1, pos1, user1, l21) = outs
+    assert torch.equal(ic1[:, :D], item16[i[0].long()].float())
+    assert torch.equal(ic0[:, :D], t[0][i[0].long()])
+    assert torch.equal(ic1[:, D:], ic0[:, D:]) and torch.equal(pos1, pos0) and torch.equal(user1, user0)
+    want = float((ic1.double() ** 2).sum() + (pos1.double() ** 2).sum() + (user1.double() ** 2).sum())
+    assert abs(float(l21.double().sum()) - want) < 1e-5 * want
