@@ -111,6 +111,11 @@ def load():
         raise MtamHipError(
             "libmtam_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C mtamrecommender_amd/csrc`" % LIB_PATH)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 and the device memory comes from it, so it
+    # has to be the copy this library binds to.  Loaded the other way round (this library first, against
+    # /opt/rocm's runtime, torch afterwards) the process holds two runtimes and the first launch from here
+    # fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing

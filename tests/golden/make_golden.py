@@ -27,6 +27,9 @@ CASES = {
     "mtam_b6_l8_nb2_h2": ("MTAM", 6, 8, 128, 2, 2, 90, 7, 25, 11),
     "mtam_b16_l50_nb1_h1": ("MTAM", 16, 50, 128, 1, 1, 300, 17, 40, 12),
     "pistrec_b5_l10_nb2_h1": ("PISTRec", 5, 10, 128, 2, 1, 80, 6, 20, 13),
+    # family members with kernels of their own (the T-SeqRec cell, the output_concat head)
+    "mtam_with_t_seqrec_b6_l8_nb1_h2": ("MTAM_with_T_SeqRec", 6, 8, 128, 1, 2, 90, 7, 25, 14),
+    "mtam_hybird_b6_l8_nb1_h1": ("MTAM_hybird", 6, 8, 128, 1, 1, 90, 7, 25, 15),
 }
 REG = 5e-5
 
@@ -46,11 +49,15 @@ def make_case(model, B, L, D, NB, H, items, cats, users, seed):
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
+    only = sys.argv[1:]
     for name, (model, B, L, D, NB, H, items, cats, users, seed) in CASES.items():
+        if only and name not in only:
+            continue
         records, feed, arrays = make_case(model, B, L, D, NB, H, items, cats, users, seed)
         out, grads, slot_sq = O.loss_and_grads(model, arrays, feed, H, NB, REG, torch.float64)
-        ref = N.forward(model, arrays, feed, H, NB, REG)
-        assert np.abs(out["logits"].detach().numpy() - ref["logits"]).max() < 1e-10
+        if model in ("MTAM", "PISTRec"):             # the second restatement covers the two main models
+            ref = N.forward(model, arrays, feed, H, NB, REG)
+            assert np.abs(out["logits"].detach().numpy() - ref["logits"]).max() < 1e-10
         logits = out["logits"].detach().numpy()
         payload = {"feed_" + k: v for k, v in feed.items()}
         payload.update({

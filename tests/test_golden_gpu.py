@@ -15,7 +15,7 @@ def test_hip_matches_golden(hip_lib, tmp_path, path):
     from mtamrecommender_amd.Embedding.Behavior_embedding_time_aware_attention import \
         Behavior_embedding_time_aware_attention
     from mtamrecommender_amd.Model.base_model import Session
-    from mtamrecommender_amd.Model.MTAMRec_model import MTAM
+    from mtamrecommender_amd.Model import MTAMRec_model as family
     from mtamrecommender_amd.Model.PISTRec_model import Time_Aware_self_Attention_model
     from tests.golden.make_golden import CASES, make_case
     name = os.path.splitext(os.path.basename(path))[0]
@@ -26,7 +26,8 @@ def test_hip_matches_golden(hip_lib, tmp_path, path):
     FLAGS.num_blocks, FLAGS.num_heads, FLAGS.length_of_user_history = NB, H, L
     FLAGS.checkpoint_path_dir = str(tmp_path)
     emb = Behavior_embedding_time_aware_attention(True, users, items, cats, L)
-    model = (MTAM if model_name == "MTAM" else Time_Aware_self_Attention_model)(FLAGS, emb, Session("cuda:0"))
+    cls = Time_Aware_self_Attention_model if model_name == "PISTRec" else getattr(family, model_name)
+    model = cls(FLAGS, emb, Session("cuda:0"))
     model.use_graph = False
     model.set_variables(arrays)
     p = model.path
