@@ -77,7 +77,7 @@ class base_model(object):
         self.logger = create_log().logger
         self.path = None            # TimeAwarePath, built by build_model()
         self.use_graph = os.environ.get("MTAM_HIP_GRAPH", "1") != "0"
-        self._dp_mode = os.environ.get("MTAM_DP_GRAPH", "fused")
+        self._dp_mode = os.environ.get("MTAM_DP_GRAPH")       # None: decided at the first data-parallel step
         self._graphs = {}
 
     # ------------------------------------------------------------ life cycle
@@ -220,14 +220,18 @@ class base_model(object):
         """One training step on the feed already in ``bt.arena``.
 
         Data parallel: the RCCL all-reduce sits between backward and update.  ``MTAM_DP_GRAPH``:
-        ``fused`` (default) captures forward, backward, the collective and the update into ONE
-        hipGraph (RCCL enqueues into the capturing stream; thread-local capture mode keeps the
-        process group's watchdog thread from invalidating it); if that capture raises, or with
-        ``split``, the step is two graphs with the collective launched between them."""
+        ``fused`` captures forward, backward, the collective and the update into ONE hipGraph (RCCL
+        enqueues into the capturing stream; thread-local capture mode keeps the process group's watchdog
+        thread from invalidating it); if that capture raises, or with ``split``, the step is two graphs
+        with the collective launched eagerly between them.  Default: ``split`` for more than one rank --
+        the fused form has only been run with a one-rank group (this build's GPU box has one GPU), and a
+        collective that misbehaves inside a replayed graph cannot be recovered from -- ``fused`` otherwise."""
         p = self.path
         if p.allreduce_fn is None:
             self._run("train", bt, p.train_kernels)
             return
+        if self._dp_mode is None:
+            self._dp_mode = "fused" if p.world_size == 1 else "split"
         if self._dp_mode == "fused":
             try:
                 self._run("train_dp", bt, p.train_kernels, capture_error_mode="thread_local")
