@@ -287,6 +287,23 @@ def main():
                                      if (L, B_PER_GPU) == (50, 128) else None,
                                      "bytes_per_launch": sb, "us_per_launch": t_scatter * 1e6},
         }
+        if args.score_dtype == "bf16":
+            # the two catalog passes of the bf16 scoring (csrc/score16.hip): algorithmic bytes per catalog row =
+            # 256 (bf16 row, lse pass) and 256 + 512 (bf16 row read, fp32 gradient row written; backward)
+            V, reps = p.item_rows, (50 if p.item_rows < 2000000 else 3)
+            tgt = fd["target_item_id"]
+            t_lse = time_kernel(lambda: ops.score16_lse(p.item16, bt.pred16, tgt, B_PER_GPU, V, bt.s16_partial, bt.lse,
+                                                        bt.ce), torch, reps=reps, replays=5)
+            sq = bt.norm_partial[p.nb_dense:]
+            t_bwd = time_kernel(lambda: ops.score16_bwd(p.item16, bt.pred16, bt.lse, tgt, B_PER_GPU, V,
+                                                        1.0 / (B_PER_GPU * world), bt.d_pred, p.g_tab["item"], sq),
+                                torch, reps=reps, replays=5)
+            for key, kernel, t, nbytes in (("roofline_score16_lse", "score16_lse_kernel", t_lse, V * 256.0),
+                                           ("roofline_score16_bwd", "score16_bwd_kernel", t_bwd, V * 768.0)):
+                result[key] = {"kernel": kernel, "bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "bytes_per_launch": nbytes, "us_per_launch": t * 1e6}
+            log("score16 lse %.1f us, backward %.1f us per launch" % (t_lse * 1e6, t_bwd * 1e6))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(batches[:8], FLAGS, arrays0, model_name=args.model)
         sys.stdout.flush()
