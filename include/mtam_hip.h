@@ -388,6 +388,20 @@ int mtam_score16_bwd(const uint16_t *E16, const uint16_t *P16, const float *lse,
 int mtam_score16_logits(const uint16_t *E16, const uint16_t *P16, int B, int V, float *logits, long ld,
                         void *stream);
 
+/* ------------------------------------------- fp32 scoring without logits (launch-bound catalogs)
+ * The pair above with fp32 operands on v_mfma_f32_32x32x2_f32: E [V, 128] and pred [B, 128] as they are
+ * (no copies, no padding).  Meant for catalogs where the step is bound by launches, not bytes (ml-1m):
+ * it replaces the logits GEMM, mtam_softmax_ce and the two scoring-gradient GEMMs of a training step.
+ * Evaluation keeps the stored-logits GEMM (its k-ordered fmaf chain is the ranking contract of mtam_topk).
+ *   partial: mtam_score32_partials(B, V) floats; sq_partial: mtam_score32_sq_partials(V) floats or NULL;
+ *   d_pred is accumulated (the caller zeroes it), dE [V, 128] is stored. */
+int mtam_score32_partials(int B, int V);
+int mtam_score32_sq_partials(int V);
+int mtam_score32_lse(const float *E, const float *pred, const int32_t *target, int B, int V, float *partial,
+                     float *lse, float *ce, void *stream);
+int mtam_score32_bwd(const float *E, const float *pred, const float *lse, const int32_t *target, int B, int V,
+                     float scale, float *d_pred, float *dE, float *sq_partial, void *stream);
+
 /* ------------------------------------------------------------------ top-K
  * tf.nn.top_k (Model/base_model.py:196-200): for every row the k largest
  * scores, descending, equal values -> lower index first.  k <= 64.

@@ -21,6 +21,8 @@ hipGraph (``torch.cuda.CUDAGraph``) and replayed; the only per-step input is
 the feed arena.  Data-parallel training calls ``allreduce_fn`` between
 backward and update (``data_parallel.py``).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -103,6 +105,8 @@ class _Batch(object):
         self.logits_store = f(B, self.ld_logits)
         self.logits = self.logits_store[:, :V]
         self.lse, self.ce = f(B), f(B)
+        if path.logits_free32:
+            self.s32_partial = f(ops.score32_partials(B, V))
         if path.score_dtype == "bf16":
             self.pred16 = torch.zeros((ops.score16_batch_pad(B), D), dtype=torch.bfloat16, device=dev)
             self.s16_partial = f(ops.score16_partials(B, V))
@@ -202,6 +206,15 @@ class TimeAwarePath(object):
         self.nb_dense = ops.sqnorm_blocks(self.n_dense)
         # the dense item gradient's squared norm comes out of its GEMM's epilogue (one partial per wave)
         self.nb_item = ops.gemm_sq_partials(self.item_rows, D)
+        # fp32 training on a small catalog is bound by launches, not bytes: score without stored logits there
+        # (csrc/score32.hip: three launches instead of four, no [B, V] round trips).  Measured per step at
+        # B=128: 3,709 rows 0.3012 vs 0.3049 ms, 8,003 rows 0.3128 vs 0.3095, 30,003 rows 0.379 vs 0.352 --
+        # every 32-row slab flushes a [128, 128] share of d_pred by atomics, which stops paying beyond a few
+        # thousand rows.  MTAM_FUSED_SCORE_MAX_ROWS overrides the limit (0 = never)
+        self.logits_free32 = score_dtype == "f32" and \
+            self.item_rows <= int(os.environ.get("MTAM_FUSED_SCORE_MAX_ROWS", "4096"))
+        if self.logits_free32:
+            self.nb_item = ops.score32_sq_partials(self.item_rows)
         self.item16 = None
         if score_dtype == "bf16":
             self.nb_item = ops.score16_sq_partials(self.item_rows)
@@ -258,10 +271,14 @@ class TimeAwarePath(object):
     def score_forward(self, bt, training):
         """logits = pred . E^T (Model/base_model.py:309-312).  bf16 training keeps no logits: it goes
         straight to lse / cross entropy."""
+        V = self.item_rows
+        if self.logits_free32 and training:
+            ops.score32_lse(self.tables["item"], bt.pred, bt.feed["target_item_id"], bt.B, V, bt.s32_partial,
+                            bt.lse, bt.ce)
+            return
         if self.score_dtype == "f32":
             ops.gemm(bt.pred, self.tables["item"], bt.logits_store, trans_b=True)
             return
-        V = self.item_rows
         ops.f32_to_bf16(bt.pred.view(-1), bt.pred16.view(-1))
         if training:
             ops.score16_lse(self.item16, bt.pred16, bt.feed["target_item_id"], bt.B, V, bt.s16_partial, bt.lse, bt.ce)
@@ -272,6 +289,10 @@ class TimeAwarePath(object):
         """dE (every row; its share of the TF global norm on the way out) and d_pred (accumulated)."""
         part, V = bt.norm_partial, self.item_rows
         sq = part[self.nb_dense:] if self.tf_compat else None
+        if self.logits_free32:
+            ops.score32_bwd(self.tables["item"], bt.pred, bt.lse, bt.feed["target_item_id"], bt.B, V,
+                            1.0 / (bt.B * self.world_size), bt.d_pred, self.g_tab["item"], sq)
+            return
         if self.score_dtype == "bf16":
             gb = bt.B * self.world_size
             ops.score16_bwd(self.item16, bt.pred16, bt.lse, bt.feed["target_item_id"], bt.B, V, 1.0 / gb,
@@ -346,7 +367,7 @@ class TimeAwarePath(object):
         self.score_forward(bt, training)
 
     def loss_and_logit_grad(self, bt):
-        if self.score_dtype == "bf16":
+        if self.score_dtype == "bf16" or self.logits_free32:
             return              # lse and cross entropy came out of score_forward; G is formed inside score_backward
         B, V = bt.B, self.item_rows
         gb = B * self.world_size

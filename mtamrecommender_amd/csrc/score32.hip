@@ -1,0 +1,326 @@
+// fp32 catalog scoring without stored logits, for catalogs small enough that the step is bound by launches
+// rather than bytes (ml-1m: 3,709 rows): the training loss and both scoring gradients of
+// base_model.output (Model/base_model.py:300-328, 290-297) in TWO launches instead of four
+// (logits GEMM, softmax-CE, dE GEMM, d_pred GEMM) and without the [B, V] round trips between them.
+//
+//   score32_lse   scores of a 32-row catalog slab on v_mfma_f32_32x32x2_f32, per-row running (max, sum-exp)
+//   score32_bwd   recomputes the slab's scores, forms G = (softmax - onehot) * scale in registers, and
+//                 produces dE (stored, with its squared norm) and the workgroup's share of d_pred (atomics)
+//
+// Same structure as csrc/score16.hip with fp32 operands: lane l (r = l & 31, h = l >> 5) of the 32x32x2
+// instruction supplies A[row r][k = h] and B[k = h][col r]; k-step s pairs element s (lane half 0) with
+// element s + 64 (lane half 1) of a 128-long contraction, so a lane's resident operand is 64 contiguous
+// floats, and a staged row keeps its two halves one float apart ([64][gap][64][gap], 130 floats): the
+// 64 lanes of a fragment read then hit 64 distinct LDS banks.  fp32 products, fp32 accumulation (two
+// independent accumulator chains per tile: a dependent MFMA issues every ~84 cycles, an independent one
+// every 64).  Evaluation keeps the stored-logits GEMM (its k-ordered fmaf chain is the ranking contract).
+#include "common.h"
+
+namespace {
+
+constexpr int D = MTAM_D;
+constexpr int SLAB = 32;        // catalog rows per iteration
+constexpr int BT = 128;         // batch rows per tile
+constexpr int PITCH = 130;      // floats per staged 128-float row
+constexpr int GT_PITCH = 34;    // floats per G^T row: [16][gap][16][gap]
+constexpr float L2E = 1.4426950408889634f;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+__device__ __forceinline__ int gap64(int c) { return c + (c >> 6); }      // position of element c in a gapped 128-row
+__device__ __forceinline__ int gap16(int c) { return c + (c >> 4); }      // ... in a gapped 32-row
+
+struct Stage {
+  f32x4 v[4];
+};
+// 32 rows x 512 B: 4 x 16 B per thread, every wave-instruction reads 1 KiB contiguous; rows past the end
+// re-read the last row (masked later)
+__device__ __forceinline__ void stage_load(Stage &st, const float *__restrict__ E, int v0, int V, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    const long v = min(v0 + (c >> 5), V - 1);
+    st.v[i] = *reinterpret_cast<const f32x4 *>(E + v * D + (c & 31) * 4);
+  }
+}
+__device__ __forceinline__ void stage_store(const Stage &st, float *buf, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    float *dst = buf + (c >> 5) * PITCH + gap64((c & 31) * 4);
+    dst[0] = st.v[i].x; dst[1] = st.v[i].y; dst[2] = st.v[i].z; dst[3] = st.v[i].w;
+  }
+}
+// this lane's 64 contiguous floats of a 128-float row (elements 64 h .. 64 h + 63)
+__device__ __forceinline__ void load_half_row(float (&p)[64], const float *__restrict__ row, int h) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const f32x4 x = *reinterpret_cast<const f32x4 *>(row + 64 * h + 4 * q);
+    p[4 * q] = x.x; p[4 * q + 1] = x.y; p[4 * q + 2] = x.z; p[4 * q + 3] = x.w;
+  }
+}
+// S[v][b] = sum_d E[v][d] P[b][d] for the slab's 32 rows and this wave's 32 batch rows
+__device__ __forceinline__ f32x16 slab_scores(const float *e_lds, const float (&p1)[64], int r, int h) {
+  f32x16 a0 = {0.f}, a1 = {0.f};
+  const float *e = e_lds + r * PITCH + 65 * h;
+#pragma unroll
+  for (int s = 0; s < 64; s += 2) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(e[s], p1[s], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(e[s + 1], p1[s + 1], a1, 0, 0, 0);
+  }
+  return a0 + a1;
+}
+
+// ------------------------------------------------------------------ forward: log-sum-exp without logits
+__global__ __launch_bounds__(256) void score32_lse_kernel(const float *__restrict__ E, const float *__restrict__ P,
+                                                          int V, int B, int slabs_per_wg,
+                                                          float *__restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float e_lds[SLAB * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int chunks = gridDim.x, c = blockIdx.x;
+  const long b = (long)blockIdx.y * BT + 32 * w + r;
+  const int nslab = (V + SLAB - 1) / SLAB;
+  const int slab0 = min(c * slabs_per_wg, nslab), slab1 = min(nslab, slab0 + slabs_per_wg);
+  float p1[64];
+  load_half_row(p1, P + min(b, (long)B - 1) * D, h);
+  float m = -INFINITY, ssum = 0.f;
+  Stage st;
+  if (slab0 < slab1) stage_load(st, E, slab0 * SLAB, V, tid);
+  for (int sl = slab0; sl < slab1; ++sl) {
+    stage_store(st, e_lds, tid);
+    __syncthreads();
+    if (sl + 1 < slab1) stage_load(st, E, (sl + 1) * SLAB, V, tid);
+    f32x16 acc = slab_scores(e_lds, p1, r, h);
+    const int vbase = sl * SLAB + 4 * h;
+    const int vlim = (sl * SLAB + SLAB <= V) ? 0x7fffffff : V;
+    float mx = m;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int v = vbase + (q & 3) + 8 * (q >> 2);
+      const float x = (v < vlim) ? acc[q] : -INFINITY;
+      acc[q] = x;
+      mx = fmaxf(mx, x);
+    }
+    const float ref = (mx == -INFINITY) ? 0.f : mx;
+    const float nref = -ref * L2E;
+    float add = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) add += fast_exp2(fmaf(acc[q], L2E, nref));
+    ssum = ssum * fast_exp2(fmaf(m, L2E, nref)) + add;
+    m = mx;
+    __syncthreads();
+  }
+  const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(ssum, 32, 64);
+  const float mm = fmaxf(m, m2), ref = (mm == -INFINITY) ? 0.f : mm;
+  const float ss = ssum * fast_exp2((m - ref) * L2E) + s2 * fast_exp2((m2 - ref) * L2E);
+  if (h == 0 && b < B) {
+    partial[((size_t)b * chunks + c) * 2 + 0] = mm;
+    partial[((size_t)b * chunks + c) * 2 + 1] = ss;
+  }
+}
+
+__global__ __launch_bounds__(256) void score32_finish_kernel(const float *__restrict__ E, const float *__restrict__ P,
+                                                             const int32_t *__restrict__ target, int V, int chunks,
+                                                             const float *__restrict__ partial,
+                                                             float *__restrict__ lse, float *__restrict__ ce) {
+  __shared__ float red[4], red2[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *pp = partial + (size_t)b * chunks * 2;
+  // all loads first: the target row and this row's partials
+  const long t = min(max(target[b], 0), V - 1);
+  float dot = (tid < D) ? P[(size_t)b * D + tid] * E[t * D + tid] : 0.f;
+  float m = -INFINITY;
+  for (int c = tid; c < chunks; c += 256) m = fmaxf(m, pp[2 * c]);
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = tid; c < chunks; c += 256) s += pp[2 * c + 1] * expf(pp[2 * c] - m);
+  s = wave_sum(s);
+  dot = wave_sum(dot);
+  if ((tid & 63) == 0) {
+    red[tid >> 6] = s;
+    red2[tid >> 6] = dot;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float l = m + logf((red[0] + red[1]) + (red[2] + red[3]));
+    lse[b] = l;
+    ce[b] = l - ((red2[0] + red2[1]) + (red2[2] + red2[3]));
+  }
+}
+
+// ------------------------------------------------------------------ backward: G, d_pred and dE in one pass
+struct BwdArgs {
+  const float *E, *P;         // P, lse, target, d_pred: already moved to this launch's 128-row batch tile
+  const float *lse;
+  const int32_t *target;
+  int V, Bt, slabs_per_wg;
+  float scale;
+  float *d_pred, *dE, *sq_partial;
+};
+
+template <bool RMW>
+__global__ __launch_bounds__(256) void score32_bwd_kernel(BwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float e_lds[SLAB * PITCH];
+  __shared__ __attribute__((aligned(16))) float g_lds[SLAB * PITCH];      // G[v][b], gapped at b = 64
+  __shared__ __attribute__((aligned(16))) float gt_lds[BT * GT_PITCH];    // G^T[b][v], gapped at v = 16
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int V = p.V;
+  const int nslab = (V + SLAB - 1) / SLAB;
+  const int slab0 = min((int)blockIdx.x * p.slabs_per_wg, nslab), slab1 = min(nslab, slab0 + p.slabs_per_wg);
+  const int dcol = 32 * w + r;        // this lane's output column in both backward products
+  const int bcol = 32 * w + r;        // the batch row (of the tile) whose scores sit on this lane
+  const bool valid_b = bcol < p.Bt;
+  const int brow = min(bcol, p.Bt - 1);
+  // a batch row that does not exist gets c_b = -inf and no target: G = 0 without a mask
+  const float c_b = valid_b ? fmaf(-p.lse[brow], L2E, log2f(p.scale)) : -INFINITY;
+  const int t_b = valid_b ? min(max(p.target[brow], 0), V - 1) : -1;
+  float p1[64], p2[64];
+  load_half_row(p1, p.P + (size_t)brow * D, h);
+  // pred[b = s + 64 h][d = dcol]: the k operand of dE (rows past the tile: any valid row, their G is 0)
+#pragma unroll
+  for (int s = 0; s < 64; ++s) p2[s] = p.P[(size_t)min(s + 64 * h, p.Bt - 1) * D + dcol];
+  f32x16 dp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dp[i] = f32x16{0.f};
+  float sq = 0.f;
+
+  Stage st;
+  if (slab0 < slab1) stage_load(st, p.E, slab0 * SLAB, V, tid);
+  for (int sl = slab0; sl < slab1; ++sl) {
+    stage_store(st, e_lds, tid);
+    __syncthreads();
+    if (sl + 1 < slab1) stage_load(st, p.E, (sl + 1) * SLAB, V, tid);
+    const int vbase = sl * SLAB;
+    const bool full = vbase + SLAB <= V;
+    const int vlim = full ? 0x7fffffff : V;
+
+    // ---- scores of this wave's 32 batch rows, G to LDS in both orientations
+    {
+      const f32x16 acc = slab_scores(e_lds, p1, r, h);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+        const int v = vbase + row;
+        float g = fast_exp2(fmaf(acc[q], L2E, c_b)) - ((v == t_b) ? p.scale : 0.f);
+        g = (v < vlim) ? g : 0.f;
+        g_lds[row * PITCH + gap64(bcol)] = g;
+        gt_lds[bcol * GT_PITCH + gap16(row)] = g;
+      }
+    }
+    __syncthreads();
+
+    // ---- dE[v][d] = sum_b G[v][b] pred[b][d]   (this wave: columns d = 32 w ..)
+    {
+      f32x16 a0 = {0.f}, a1 = {0.f};
+      const float *g = g_lds + r * PITCH + 65 * h;
+#pragma unroll
+      for (int s = 0; s < 64; s += 2) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s], p2[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g[s + 1], p2[s + 1], a1, 0, 0, 0);
+      }
+      f32x16 acc = a0 + a1;
+      float *const out = p.dE + ((size_t)vbase + 4 * h) * D + dcol;
+      if (RMW) {
+        float old[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          old[q] = out[(long)min((q & 3) + 8 * (q >> 2), V - 1 - vbase - 4 * h) * D];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += old[q];
+      }
+      if (full) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          sq = fmaf(acc[q], acc[q], sq);
+          out[(size_t)((q & 3) + 8 * (q >> 2)) * D] = acc[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = (q & 3) + 8 * (q >> 2);
+          if (vbase + row + 4 * h < V) {
+            sq = fmaf(acc[q], acc[q], sq);
+            out[(size_t)row * D] = acc[q];
+          }
+        }
+      }
+    }
+
+    // ---- d_pred[b][d] += sum_v G[v][b] E[v][d]   (this wave: columns d = 32 w .., all 128 batch rows)
+    {
+      const float *eb = e_lds + (16 * h) * PITCH + gap64(dcol);
+      const float *ga = gt_lds + r * GT_PITCH + 17 * h;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float bv = eb[s * PITCH];
+#pragma unroll
+        for (int mblk = 0; mblk < 4; ++mblk)
+          dp[mblk] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[(32 * mblk) * GT_PITCH + s], bv, dp[mblk], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int mblk = 0; mblk < 4; ++mblk)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int b = 32 * mblk + acc_row(q, h);
+      if (b < p.Bt) atomicAdd(p.d_pred + b * D + dcol, dp[mblk][q]);
+    }
+  if (p.sq_partial) {
+    sq = wave_sum(sq);
+    if (lane == 0) p.sq_partial[(size_t)blockIdx.x * 4 + w] = sq;
+  }
+}
+
+int slabs_of(int V) { return (V + SLAB - 1) / SLAB; }
+int chunks_of(int V) { return max(1, min(slabs_of(V), 2048)); }
+int slabs_per_wg_of(int V) { return (slabs_of(V) + chunks_of(V) - 1) / chunks_of(V); }
+int grid_of(int V) { return (slabs_of(V) + slabs_per_wg_of(V) - 1) / slabs_per_wg_of(V); }
+
+}  // namespace
+
+extern "C" int mtam_score32_partials(int B, int V) { return B * grid_of(V) * 2; }
+extern "C" int mtam_score32_sq_partials(int V) { return grid_of(V) * 4; }
+
+extern "C" int mtam_score32_lse(const float *E, const float *pred, const int32_t *target, int B, int V,
+                                float *partial, float *lse, float *ce, void *stream) {
+  MTAM_CHECK_ARG(E && pred && target && partial && lse && ce, "score32_lse: null argument");
+  MTAM_CHECK_ARG(B > 0 && V > 0 && V < 0x7fffff00 && (B + BT - 1) / BT <= 65535, "score32_lse: bad shape B=%d V=%d", B, V);
+  MTAM_CHECK_ARG(mtam_aligned16(E) && mtam_aligned16(pred), "score32_lse: operands must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_of(V);
+  hipLaunchKernelGGL(score32_lse_kernel, dim3(grid, (B + BT - 1) / BT), dim3(256), 0, s, E, pred, V, B,
+                     slabs_per_wg_of(V), partial);
+  hipLaunchKernelGGL(score32_finish_kernel, dim3(B), dim3(256), 0, s, E, pred, target, V, grid, partial, lse, ce);
+  MTAM_CHECK_LAUNCH("score32_lse");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_score32_bwd(const float *E, const float *pred, const float *lse, const int32_t *target, int B,
+                                int V, float scale, float *d_pred, float *dE, float *sq_partial, void *stream) {
+  MTAM_CHECK_ARG(E && pred && lse && target && d_pred && dE, "score32_bwd: null argument");
+  MTAM_CHECK_ARG(B > 0 && V > 0 && V < 0x7fffff00 && scale > 0.f, "score32_bwd: bad shape B=%d V=%d", B, V);
+  MTAM_CHECK_ARG(mtam_aligned16(E) && mtam_aligned16(pred), "score32_bwd: operands must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // one launch per 128-row batch tile; a later tile adds onto the dE rows the earlier one stored
+  const int ntile = (B + BT - 1) / BT;
+  for (int tile = 0; tile < ntile; ++tile) {
+    const long b0 = (long)tile * BT;
+    BwdArgs a{E, pred + b0 * D, lse + b0, target + b0, V, (int)min((long)BT, B - b0), slabs_per_wg_of(V), scale,
+              d_pred + b0 * D, dE, tile == ntile - 1 ? sq_partial : nullptr};
+    if (tile == 0)
+      hipLaunchKernelGGL(score32_bwd_kernel<false>, dim3(grid_of(V)), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(score32_bwd_kernel<true>, dim3(grid_of(V)), dim3(256), 0, st, a);
+  }
+  MTAM_CHECK_LAUNCH("score32_bwd");
+  return MTAM_OK;
+}

@@ -318,6 +318,26 @@ def score16_bwd(E16, P16, lse, target, B, V, scale, d_pred, dE, sq_partial=None)
                                     _p(dE), _p(sq_partial), _stream()), "mtam_score16_bwd")
 
 
+def score32_partials(B, V):
+    return _lib.load().mtam_score32_partials(B, V)
+
+
+def score32_sq_partials(V):
+    return _lib.load().mtam_score32_sq_partials(V)
+
+
+def score32_lse(E, pred, target, B, V, partial, lse, ce):
+    lib = _lib.load()
+    _lib.check(lib.mtam_score32_lse(_p(E), _p(pred), _pi(target), B, V, _p(partial), _p(lse), _p(ce), _stream()),
+               "mtam_score32_lse")
+
+
+def score32_bwd(E, pred, lse, target, B, V, scale, d_pred, dE, sq_partial=None):
+    lib = _lib.load()
+    _lib.check(lib.mtam_score32_bwd(_p(E), _p(pred), _p(lse), _pi(target), B, V, float(scale), _p(d_pred), _p(dE),
+                                    _p(sq_partial), _stream()), "mtam_score32_bwd")
+
+
 def score16_logits(E16, P16, B, V, logits, ld):
     lib = _lib.load()
     _lib.check(lib.mtam_score16_logits(_pb(E16), _pb(P16), B, V, _p(logits), ld, _stream()), "mtam_score16_logits")

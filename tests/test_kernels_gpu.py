@@ -840,3 +840,36 @@ def test_gather_reads_item_rows_from_the_bf16_copy(ops):
     assert torch.equal(ic1[:, D:], ic0[:, D:]) and torch.equal(pos1, pos0) and torch.equal(user1, user0)
     want = float((ic1.double() ** 2).sum() + (pos1.double() ** 2).sum() + (user1.double() ** 2).sum())
     assert abs(float(l21.double().sum()) - want) < 1e-5 * want
+
+
+@pytest.mark.parametrize("B,V", [(128, 3709), (100, 1000), (37, 63), (256, 7001), (130, 70007)])
+def test_score32_lse_and_backward(ops, B, V):
+    """csrc/score32.hip (fp32 logits-free scoring) against float64 products of the same fp32 operands:
+    fp32 products and sums, so 2e-5 of the largest entry (G itself is formed in fp32 here)."""
+    rng = np.random.default_rng(B * 3 + V)
+    E = dev((rng.standard_normal((V, D)) * 0.2).astype(np.float32))
+    P = dev(rng.standard_normal((B, D)).astype(np.float32))
+    target = rng.integers(0, V, B).astype(np.int32)
+    target[0] = V - 1
+    tgt = dev(target)
+    lse = torch.zeros(B, device="cuda")
+    ce = torch.zeros(B, device="cuda")
+    partial = torch.zeros(ops.score32_partials(B, V), device="cuda")
+    ops.score32_lse(E, P, tgt, B, V, partial, lse, ce)
+    ref_logits = P.double() @ E.double().T
+    ref_lse = torch.logsumexp(ref_logits, 1)
+    ref_ce = ref_lse - ref_logits.gather(1, tgt.long()[:, None])[:, 0]
+    assert float((lse.double() - ref_lse).abs().max()) < 1e-5 * float(ref_lse.abs().max())
+    assert float((ce.double() - ref_ce).abs().max()) < 2e-5 * float(ref_lse.abs().max())
+    scale = 1.0 / B
+    G = torch.exp(ref_logits - ref_lse[:, None])
+    G[torch.arange(B), tgt.long()] -= 1.0
+    G *= scale
+    ref_dpred, ref_dE = G @ E.double(), G.T @ P.double()
+    d_pred = torch.zeros((B, D), device="cuda")
+    dE = torch.full((V, D), 5.0, device="cuda")
+    sq = torch.zeros(ops.score32_sq_partials(V), device="cuda")
+    ops.score32_bwd(E, P, lse, tgt, B, V, scale, d_pred, dE, sq)
+    assert float((d_pred.double() - ref_dpred).abs().max()) < 2e-5 * float(ref_dpred.abs().max())
+    assert float((dE.double() - ref_dE).abs().max()) < 2e-5 * float(ref_dE.abs().max())
+    assert abs(float(sq.double().sum()) - float((dE.double() ** 2).sum())) < 1e-5 * float((dE.double() ** 2).sum())
