@@ -402,6 +402,16 @@ int mtam_score32_lse(const float *E, const float *pred, const int32_t *target, i
 int mtam_score32_bwd(const float *E, const float *pred, const float *lse, const int32_t *target, int B, int V,
                      float scale, float *d_pred, float *dE, float *sq_partial, void *stream);
 
+/* ------------------------------------------- the forward's three sequence-side projections in one launch
+ *   zr = relu(ic W4) ; x = zr + pos                       (Embedding/...attention.py:95-103; = mtam_gemm_f32 RELU_ADD)
+ *   kv = relu(x Wkv + bkv)  [R, n_kv]   (n_kv may be 0)    (time_aware_attention.py:251-253;   = BIAS_RELU)
+ *   xproj = x Wx + bx       [R, n_x]                       (time_aware_rnn.py:243-256, input halves; = BIAS)
+ * ic [R, 256], W4 [256, 128], pos [R, 128], Wkv [128, n_kv], Wx [128, n_x]; n_kv, n_x multiples of 32;
+ * every output 16-byte aligned.  A workgroup owns a 32-row stripe; x stays on the CU between the products. */
+int mtam_seq_chain_fwd(const float *ic, const float *W4, const float *pos, int R, const float *Wkv,
+                       const float *bkv, int n_kv, const float *Wx, const float *bx, int n_x, float *zr, float *x,
+                       float *kv, float *xproj, void *stream);
+
 /* ------------------------------------------------------------------ top-K
  * tf.nn.top_k (Model/base_model.py:196-200): for every row the k largest
  * scores, descending, equal values -> lower index first.  k <= 64.

@@ -321,10 +321,21 @@ class TimeAwarePath(object):
                            # a training step's first kernel also clears its gradient accumulators
                            clear=(self.zero_prefix, bt.d_clear if cfg["keys"] == "gru" else bt.d_pred.view(-1))
                            if training else (), item16=self.item16)
-        ops.gemm(bt.ic, self.seg("dense4emb/w"), bt.x, epilogue=ops.EPI_RELU_ADD, aux_in=bt.pos, aux_out=bt.zr)
         keys = bt.hs if cfg["keys"] == "gru" else bt.x        # user_history: what the decoder attends over
-        if cfg["attention"] and cfg["keys"] == "x":           # keys/values of every block (before the GRU)
-            ops.gemm(bt.x, self.seg("kv/w"), bt.kv, epilogue=ops.EPI_BIAS_RELU, bias=self.seg("kv/b"))
+        kv_from_x = cfg["attention"] and cfg["keys"] == "x"    # keys/values of every block (before the GRU)
+        # dense4emb, the K/V projection and the GRU's input projection in ONE launch (a 32-row stripe of x
+        # stays on its CU; 16-byte stores): 25.5 us against 35.4 us as three GEMMs at 6,400 rows.
+        # MTAM_SEQ_CHAIN=0 keeps the three GEMMs.
+        chain = cfg["gru"] != "seqrec" and os.environ.get("MTAM_SEQ_CHAIN", "1") != "0"
+        if chain:
+            ops.seq_chain_fwd(bt.ic, self.seg("dense4emb/w"), bt.pos, R,
+                              self.seg("kv/w") if kv_from_x else None, self.seg("kv/b") if kv_from_x else None,
+                              self.seg("gru/wx"), self.seg("gru/bx"), bt.zr, bt.x, bt.kv if kv_from_x else None,
+                              bt.xproj)
+        else:
+            ops.gemm(bt.ic, self.seg("dense4emb/w"), bt.x, epilogue=ops.EPI_RELU_ADD, aux_in=bt.pos, aux_out=bt.zr)
+            if kv_from_x:
+                ops.gemm(bt.x, self.seg("kv/w"), bt.kv, epilogue=ops.EPI_BIAS_RELU, bias=self.seg("kv/b"))
         if cfg["gru"] == "seqrec":
             # TimeAwareGRUCell_sigmoid: gate and candidate input halves (columns 0 .. 3 D) and the two
             # state-independent time gates  x Wk + tanh(t w + b) Wt + bias  (columns 3 D .. 5 D) in one buffer
@@ -339,7 +350,8 @@ class TimeAwarePath(object):
             ops.tagru_seqrec_fwd(bt.xproj, fd["seq_length"], self.seg("gru/wh_g"), self.seg("gru/wh_c"), B, L,
                                  bt.hs, bt.short, bt.gru_save if training else None)
         else:
-            ops.gemm(bt.x, self.seg("gru/wx"), bt.xproj, epilogue=ops.EPI_BIAS, bias=self.seg("gru/bx"))
+            if not chain:
+                ops.gemm(bt.x, self.seg("gru/wx"), bt.xproj, epilogue=ops.EPI_BIAS, bias=self.seg("gru/bx"))
             tvec = self.seg("gru/tvec") if cfg["gru"] == "time" else None
             ops.tagru_fwd(bt.xproj, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
                           self.seg("gru/wh_c"), tvec, B, L, bt.hs, bt.short, bt.gru_save if training else None)

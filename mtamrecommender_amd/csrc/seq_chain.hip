@@ -2,9 +2,12 @@
 //   z = [item | category] W4 ; zr = relu(z) ; x = zr + position     Embedding/Behavior_embedding_time_aware_attention.py:95-103
 //   kv    = relu(x Wkv + bkv)        keys / values of every decoder block       Model/Modules/time_aware_attention.py:251-253
 //   xproj = x Wx + bx                input halves of the GRU's gate / candidate products   Model/Modules/time_aware_rnn.py:243-256
-// As three GEMM launches they took 11.1 + 10.9 + 13.4 us at B x L = 6,400 rows (27 % of the fp32 MFMA rate:
-// 200-600 tiles with a K of 128-256 are all prologue and epilogue).  Here a workgroup owns a 32-row stripe:
-// the stripe of x never leaves the CU between the first product and the other two.
+// As three GEMM launches they took 11.1 + 10.9 + 13.4 us at B x L = 6,400 rows.  Here a workgroup owns a
+// 32-row stripe: the stripe of x never leaves the CU between the first product and the other two -- 25.5 us.
+// What that needed (tools lab, per launch): with every accumulator register stored as it lies (its column
+// on the lane: 16 four-byte stores of 128-byte segments per tile and lane) the kernel took 34.3 us, 21.8 with
+// the stores removed: store ISSUE, not bandwidth (22.9 MB).  Transposed through a wave-private LDS scratch
+// a tile leaves as 4 sixteen-byte stores per lane and the stores cost 3.7 us.
 //
 // v_mfma_f32_32x32x2_f32: lane l (r = l & 31, h = l >> 5) supplies A[row r][k = h] and B[k = h][col r].
 // k-step s of a K-long contraction pairs element s (lane half 0) with element s + K/2 (half 1); staged
@@ -22,6 +25,22 @@ constexpr int X_PITCH = D + 2;        // staged x row: [64][gap][64][gap]
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int T_PITCH = 36;           // transposition scratch: 32 rows x (32 + 4) floats per wave
+// A 32 x 32 accumulator tile has its column on the lane (16 four-byte stores of 128-byte segments per lane):
+// through a wave-private LDS scratch it leaves as 4 sixteen-byte stores per lane (8 rows x 128 B each).
+__device__ __forceinline__ void store_tile(float *scratch, const f32x16 &v, float *out, long row0, int R, int ld,
+                                           int col0, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) scratch[((q & 3) + 8 * (q >> 2) + 4 * h) * T_PITCH + r] = v[q];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = i * 64 + lane, row = idx >> 3, c4 = idx & 7;
+    const f32x4 t = *reinterpret_cast<const f32x4 *>(scratch + row * T_PITCH + 4 * c4);
+    if (row0 + row < R) *reinterpret_cast<f32x4 *>(out + (row0 + row) * ld + col0 + 4 * c4) = t;
+  }
+}
 
 struct ChainArgs {
   const float *ic, *W4, *pos;
@@ -69,6 +88,7 @@ __global__ __launch_bounds__(256) void seq_chain_fwd_kernel(ChainArgs p) {
   __syncthreads();
 
   // ---- z = ic . W4 (K = 256): this wave's 32 columns
+  f32x16 zr16, x16;
   {
     f32x16 a0 = {0.f}, a1 = {0.f};
     const float *a = a_lds + r * A_PITCH + (D + 1) * h;
@@ -82,16 +102,15 @@ __global__ __launch_bounds__(256) void seq_chain_fwd_kernel(ChainArgs p) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int rr = (q & 3) + 8 * (q >> 2) + 4 * h;
-      const float zr = fmaxf(z[q], 0.f);
-      const float xv = zr + pv[q];
-      x_lds[rr * X_PITCH + col + (col >> 6)] = xv;
-      if (row0 + rr < R) {
-        p.zr[(row0 + rr) * D + col] = zr;
-        p.x[(row0 + rr) * D + col] = xv;
-      }
+      zr16[q] = fmaxf(z[q], 0.f);
+      x16[q] = zr16[q] + pv[q];
+      x_lds[rr * X_PITCH + col + (col >> 6)] = x16[q];
     }
   }
   __syncthreads();
+  float *scratch = a_lds + w * (ROWS * T_PITCH);      // the staged input stripe is dead: wave-private scratch
+  store_tile(scratch, zr16, p.zr, row0, R, D, 32 * w, lane);
+  store_tile(scratch, x16, p.x, row0, R, D, 32 * w, lane);
 
   // ---- kv = relu(x Wkv + bkv), xproj = x Wx + bx (K = 128): the A fragments of the stripe stay in
   // registers for every column block; column blocks of both outputs are dealt round-robin to the waves
@@ -121,13 +140,13 @@ __global__ __launch_bounds__(256) void seq_chain_fwd_kernel(ChainArgs p) {
     const bool is_kv = j < nb_kv;
     float *out = is_kv ? p.kv : p.xproj;
     const int ldo = is_kv ? p.n_kv : p.n_x, col = 32 * (is_kv ? j : j - nb_kv) + r;
+    f32x16 o;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const long row = row0 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      float v = acc[q] + bias;
-      if (is_kv) v = fmaxf(v, 0.f);
-      if (row < R) out[row * ldo + col] = v;
+      const float v = acc[q] + bias;
+      o[q] = is_kv ? fmaxf(v, 0.f) : v;
     }
+    store_tile(scratch, o, out, row0, R, ldo, col - r, lane);
   };
   // software pipeline over this wave's blocks j = w, w + 4, ...: block j + 4's weights load while j computes
   float bwA[64], bwB[64], biasA = 0.f, biasB = 0.f;

@@ -318,6 +318,15 @@ def score16_bwd(E16, P16, lse, target, B, V, scale, d_pred, dE, sq_partial=None)
                                     _p(dE), _p(sq_partial), _stream()), "mtam_score16_bwd")
 
 
+def seq_chain_fwd(ic, W4, pos, R, Wkv, bkv, Wx, bx, zr, x, kv, xproj):
+    """zr, x, kv (optional: Wkv None), xproj from [item | category] rows in one launch."""
+    lib = _lib.load()
+    n_kv = Wkv.shape[1] if Wkv is not None else 0
+    _lib.check(lib.mtam_seq_chain_fwd(_p(ic), _p(W4), _p(pos), R, _p(Wkv), _p(bkv), n_kv, _p(Wx), _p(bx),
+                                      Wx.shape[1], _p(zr), _p(x), _p(kv) if n_kv else None, _p(xproj), _stream()),
+               "mtam_seq_chain_fwd")
+
+
 def score32_partials(B, V):
     return _lib.load().mtam_score32_partials(B, V)
 

@@ -873,3 +873,33 @@ def test_score32_lse_and_backward(ops, B, V):
     assert float((d_pred.double() - ref_dpred).abs().max()) < 2e-5 * float(ref_dpred.abs().max())
     assert float((dE.double() - ref_dE).abs().max()) < 2e-5 * float(ref_dE.abs().max())
     assert abs(float(sq.double().sum()) - float((dE.double() ** 2).sum())) < 1e-5 * float((dE.double() ** 2).sum())
+
+
+@pytest.mark.parametrize("R,n_kv,n_x", [(6400, 256, 384), (100, 512, 384), (33, 0, 384), (777, 256, 640)])
+def test_seq_chain_fwd_matches_the_three_products(ops, R, n_kv, n_x):
+    """mtam_seq_chain_fwd = dense4emb (relu, + position), K/V projection (bias, relu) and the GRU input
+    projection (bias) of the forward step; float64 reference, fp32 MFMA sums: 2e-5 of the largest entry."""
+    rng = np.random.default_rng(R + n_kv + n_x)
+    ic = rng.standard_normal((R, 2 * D)).astype(np.float32)
+    pos = rng.standard_normal((R, D)).astype(np.float32)
+    W4 = (rng.standard_normal((2 * D, D)) * 0.1).astype(np.float32)
+    Wkv = (rng.standard_normal((D, max(n_kv, 32))) * 0.1).astype(np.float32)[:, :n_kv]
+    bkv = rng.standard_normal(n_kv).astype(np.float32)
+    Wx = (rng.standard_normal((D, n_x)) * 0.1).astype(np.float32)
+    bx = rng.standard_normal(n_x).astype(np.float32)
+    zr = torch.full((R, D), 9.0, device="cuda")
+    x = torch.full((R, D), 9.0, device="cuda")
+    kv = torch.full((R, max(n_kv, 1)), 9.0, device="cuda")
+    xproj = torch.full((R, n_x), 9.0, device="cuda")
+    ops.seq_chain_fwd(dev(ic), dev(W4), dev(pos), R, dev(np.ascontiguousarray(Wkv)) if n_kv else None,
+                      dev(bkv) if n_kv else None, dev(Wx), dev(bx), zr, x, kv if n_kv else None, xproj)
+    z64 = ic.astype(np.float64) @ W4.astype(np.float64)
+    zr64 = np.maximum(z64, 0.0)
+    x64 = zr64 + pos
+    assert rel_err(zr.cpu().numpy(), zr64) < 2e-5 and rel_err(x.cpu().numpy(), x64) < 2e-5
+    assert rel_err(xproj.cpu().numpy(), x64 @ Wx.astype(np.float64) + bx) < 2e-5
+    if n_kv:
+        assert rel_err(kv.cpu().numpy(), np.maximum(x64 @ Wkv.astype(np.float64) + bkv, 0.0)) < 2e-5
+    # the relu mask the backward uses is exact where the pre-activation is not within rounding of zero
+    clear = np.abs(z64) > 1e-4
+    assert np.array_equal((zr.cpu().numpy() > 0)[clear], (z64 > 0)[clear])
