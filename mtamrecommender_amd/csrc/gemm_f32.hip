@@ -41,6 +41,9 @@ struct GemmArgs {
   // optional second source accumulated into the same output tile (same transposes; no split-K)
   const float *A2, *B2;
   int K2, lda2, ldb2, vec2;
+  // C (and aux_in / aux_out / the bias-row matrix, where the epilogue uses them) 16-byte aligned with
+  // leading dimensions that are multiples of 4: the epilogue may move whole float4 row pieces
+  int vecC;
 };
 
 // Source laid out src[r][k] (k contiguous): tile of 64 rows x 32 k.
@@ -192,6 +195,69 @@ __device__ __forceinline__ float store_acc(const GemmArgs &p, const f32x16 &acc,
 // MW = 32-row blocks per wave: 1 -> the 64x64 workgroup tile; 2 -> a 128x64 tile whose waves own 64x32
 // (two accumulators: twice the MFMA work per staged byte and two independent chains that issue back
 // to back) for problems with thousands of tiles, e.g. the [B, V] scoring products at V >= 1 M.
+// The same epilogues in ROW layout: the tile goes through a wave-private LDS scratch (32 x 36 floats) and
+// comes back as 4 float4 row pieces per lane (lane -> row 8 i + (lane >> 3), columns 4 (lane & 7) ..), so
+// that every global access of the epilogue is 16 bytes wide: 4 store instructions per tile instead of 16.
+// The 4-byte stores of the column layout are store-ISSUE bound (tools: a 22.9 MB epilogue cost 12.5 us as
+// 4-byte stores, 3.7 us as 16-byte stores).  Needs the full 32-column block in range and p.vecC.
+constexpr int T_PITCH = 36;
+template <int EPI>
+__device__ __forceinline__ float store_acc_rows(const GemmArgs &p, const f32x16 &acc, float *scratch, int row0,
+                                                int col0, int lane) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  constexpr bool READ_C = EPI == MTAM_EPI_ACCUM || EPI == MTAM_EPI_ACCUM_MASK || EPI == MTAM_EPI_ACCUM2_MASK;
+  constexpr bool READ_AUX = EPI == MTAM_EPI_RELU_ADD || EPI == MTAM_EPI_ACCUM_MASK || EPI == MTAM_EPI_ACCUM2_MASK;
+  constexpr bool READ_BIAS2 = EPI == MTAM_EPI_ACCUM2_MASK;
+  constexpr bool WRITE_AUX = EPI == MTAM_EPI_RELU_ADD || EPI == MTAM_EPI_ACCUM_MASK || EPI == MTAM_EPI_ACCUM2_MASK;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) scratch[((q & 3) + 8 * (q >> 2) + 4 * h) * T_PITCH + r] = acc[q];
+  const int gn = col0 + 4 * (lane & 7);
+  v4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == MTAM_EPI_BIAS || EPI == MTAM_EPI_BIAS_RELU) bias = *reinterpret_cast<const v4 *>(p.bias + gn);
+  v4 t[4], cv[4], av[4], bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                       // every load first (clamped rows: ragged rows are not stored)
+    const int lr = 8 * i + (lane >> 3);
+    const size_t gm = min(row0 + lr, p.M - 1);
+    t[i] = *reinterpret_cast<const v4 *>(scratch + lr * T_PITCH + 4 * (lane & 7));
+    if (READ_C) cv[i] = *reinterpret_cast<const v4 *>(p.C + gm * p.ldc + gn);
+    if (READ_AUX) av[i] = *reinterpret_cast<const v4 *>(p.aux_in + gm * p.ld_aux + gn);
+    if (READ_BIAS2) bv[i] = *reinterpret_cast<const v4 *>(p.bias + gm * p.ld_aux + gn);
+  }
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = row0 + 8 * i + (lane >> 3);
+    if (gm >= p.M) continue;
+    v4 v = t[i], aux = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (EPI == MTAM_EPI_BIAS) {
+        v[c] += bias[c];
+      } else if (EPI == MTAM_EPI_BIAS_RELU) {
+        v[c] = fmaxf(v[c] + bias[c], 0.f);
+      } else if (EPI == MTAM_EPI_RELU_ADD) {
+        aux[c] = fmaxf(v[c], 0.f);
+        v[c] = aux[c] + av[i][c];
+      } else if (EPI == MTAM_EPI_ACCUM) {
+        v[c] += cv[i][c];
+      } else if (EPI == MTAM_EPI_ACCUM_MASK) {
+        v[c] += cv[i][c];
+        aux[c] = (av[i][c] > 0.f) ? v[c] : 0.f;
+      } else if (EPI == MTAM_EPI_ACCUM2_MASK) {
+        v[c] += cv[i][c] + bv[i][c];
+        aux[c] = (av[i][c] > 0.f) ? v[c] : 0.f;
+      } else if (EPI == MTAM_EPI_STORE_SQ) {
+        sq += v[c] * v[c];
+      }
+    }
+    *reinterpret_cast<v4 *>(p.C + (size_t)gm * p.ldc + gn) = v;
+    if (WRITE_AUX) *reinterpret_cast<v4 *>(p.aux_out + (size_t)gm * p.ld_aux + gn) = aux;
+  }
+  return sq;
+}
+
 template <int MW, bool TA, bool TB, int EPI>
 __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *Bs, int tile, int kslice) {
   constexpr int EA = 64 * MW;                   // A-tile rows
@@ -331,8 +397,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
 
   }   // sources
 
-  float sq = store_acc<EPI>(p, acc, m0 + wm * (32 * MW), n0 + wn * 32 + (lane & 31), lane);
-  if (MW == 2) sq += store_acc<EPI>(p, acc2, m0 + wm * 64 + 32, n0 + wn * 32 + (lane & 31), lane);
+  float sq;
+  if (EPI != MTAM_EPI_ATOMIC && p.vecC && n0 + wn * 32 + 32 <= p.N) {        // wave-uniform
+    // the operand tiles are dead (the k-loop ends on a barrier): two waves share each buffer as scratch
+    float *scratch = ((wave < 2) ? As : Bs) + (wave & 1) * (32 * T_PITCH);
+    sq = store_acc_rows<EPI>(p, acc, scratch, m0 + wm * (32 * MW), n0 + wn * 32, lane);
+    if (MW == 2) sq += store_acc_rows<EPI>(p, acc2, scratch, m0 + wm * 64 + 32, n0 + wn * 32, lane);
+  } else {
+    sq = store_acc<EPI>(p, acc, m0 + wm * (32 * MW), n0 + wn * 32 + (lane & 31), lane);
+    if (MW == 2) sq += store_acc<EPI>(p, acc2, m0 + wm * 64 + 32, n0 + wn * 32 + (lane & 31), lane);
+  }
   if (EPI == MTAM_EPI_STORE_SQ) {
     sq = wave_sum(sq);
     if (lane == 0) p.aux_out[4 * (size_t)blockIdx.x + wave] = sq;
@@ -504,6 +578,14 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float 
   a.k_chunk = k_chunk;
   a.vecA = (lda % 4 == 0) && mtam_aligned16(A);
   a.vecB = (ldb % 4 == 0) && mtam_aligned16(B);
+  {
+    const bool uses_aux = epilogue == MTAM_EPI_RELU_ADD || epilogue == MTAM_EPI_ACCUM_MASK || epilogue == MTAM_EPI_ACCUM2_MASK;
+    const bool bias_rows = epilogue == MTAM_EPI_ACCUM2_MASK;
+    const bool bias_vec = epilogue == MTAM_EPI_BIAS || epilogue == MTAM_EPI_BIAS_RELU;
+    a.vecC = (ldc % 4 == 0) && mtam_aligned16(C) &&
+             (!uses_aux || (ld_aux % 4 == 0 && mtam_aligned16(aux_in) && mtam_aligned16(aux_out))) &&
+             (!bias_rows || mtam_aligned16(bias)) && (!bias_vec || mtam_aligned16(bias));
+  }
   a.tiles_n = (int)gx;
   a.heads = 0;
   a.sA0 = a.sA1 = a.sB0 = a.sB1 = a.sC0 = a.sC1 = 0;
@@ -561,6 +643,7 @@ extern "C" int mtam_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int
   a.heads = batch1;
   a.sA0 = sA0; a.sA1 = sA1; a.sB0 = sB0; a.sB1 = sB1; a.sC0 = sC0; a.sC1 = sC1;
   a.A2 = a.B2 = nullptr; a.K2 = a.lda2 = a.ldb2 = a.vec2 = 0;
+  a.vecC = 0;
   dim3 grid((unsigned)(gx * gy), (unsigned)(batch0 * batch1), 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
   launch_trans<1>(trans_a, trans_b, epilogue, grid, s, a);
@@ -590,6 +673,7 @@ static int fill_group(int n, const MtamGemmDesc *d, GroupArgs &ga, int &blocks_o
     a.heads = 0;
     a.sA0 = a.sA1 = a.sB0 = a.sB1 = a.sC0 = a.sC1 = 0;
     a.A2 = a.B2 = nullptr; a.K2 = a.lda2 = a.ldb2 = a.vec2 = 0;
+    a.vecC = 0;
     ga.first[i] = blocks;
     blocks += a.tiles_n * ((q.M + BM - 1) / BM) * split;
   }
