@@ -114,8 +114,9 @@ def shuffled_index(n, seed):
 
 
 class PackedBatch(object):
-    """One batch already laid out as the device feed arena (pinned host memory).  The arena belongs to
-    the packer's rotating pool (3 buffers): consume the batch before two further ones are packed."""
+    """One batch already laid out as the device feed arena (pinned host memory).  The arena belongs to a
+    rotating pool of 3 buffers owned by ONE consumer (see BatchPacker.pack): consume the batch before two
+    further ones of the same consumer are packed."""
 
     def __init__(self, arena, B, index, recordset, layout):
         self.arena, self.B, self.index, self.recordset, self.layout = arena, B, index, recordset, layout
@@ -144,28 +145,41 @@ class BatchPacker(object):
                                         embedding.position_count + 3, embedding.user_count + 3)
         self.n_buffers = n_buffers
         self._layouts = {}
+        self._pools = {}
+        self._lock = threading.Lock()
 
-    def _layout(self, B):
-        if B not in self._layouts:
-            from ..Model.time_aware_path import arena_layout
-            offsets, words = arena_layout(B, self.L)
-            lay = _host_lib.ArenaLayout()
-            for k in ("user_id", "item_list", "category_list", "position_list", "target_item_id", "seq_length",
-                      "time_list", "timelast_list", "target_item_time", "lr", "timenow_list"):
-                setattr(lay, k, offsets[k][0])
-            lay.words = words
-            pin = torch.cuda.is_available()
-            pool = deque((torch.zeros(words, dtype=torch.int32).pin_memory() if pin
-                          else torch.zeros(words, dtype=torch.int32)) for _ in range(self.n_buffers))
-            self._layouts[B] = (lay, offsets, pool)
-        return self._layouts[B]
+    def _layout(self, B, consumer=None):
+        """(arena layout, field offsets, the rotating arena pool of ``consumer`` for batch size B).
+        A pool belongs to ONE consumer (one batch stream): the train stream's prefetched batch must not sit
+        in a buffer that an evaluation pass of the same batch size rotates through (round-1 advice: a shared
+        pool let the third test batch overwrite the pending train batch when the batch sizes were equal)."""
+        with self._lock:
+            if B not in self._layouts:
+                from ..Model.time_aware_path import arena_layout
+                offsets, words = arena_layout(B, self.L)
+                lay = _host_lib.ArenaLayout()
+                for k in ("user_id", "item_list", "category_list", "position_list", "target_item_id", "seq_length",
+                          "time_list", "timelast_list", "target_item_time", "lr", "timenow_list"):
+                    setattr(lay, k, offsets[k][0])
+                lay.words = words
+                self._layouts[B] = (lay, offsets)
+            lay, offsets = self._layouts[B]
+            if (B, consumer) not in self._pools:
+                pin = torch.cuda.is_available()
+                self._pools[(B, consumer)] = deque(
+                    (torch.zeros(lay.words, dtype=torch.int32).pin_memory() if pin
+                     else torch.zeros(lay.words, dtype=torch.int32)) for _ in range(self.n_buffers))
+            return lay, offsets, self._pools[(B, consumer)]
 
-    def pack(self, recordset, index, lr=0.0):
+    def pack(self, recordset, index, lr=0.0, consumer=None):
+        """``consumer``: name of the batch stream this batch belongs to (None = the packer's own default
+        pool).  Every stream rotates through its own 3 arenas."""
         index = np.ascontiguousarray(index, dtype=np.int64)
         B = len(index)
-        lay, offsets, pool = self._layout(B)
-        arena = pool[0]
-        pool.rotate(-1)
+        lay, offsets, pool = self._layout(B, consumer)
+        with self._lock:
+            arena = pool[0]
+            pool.rotate(-1)
         err = ctypes.create_string_buffer(ERR_LEN)
         rc = self._lib.mtam_pack_batch(recordset._h, _ptr(index), B, self.L, ctypes.byref(lay),
                                        ctypes.byref(self.rows), float(lr), ctypes.c_void_p(arena.data_ptr()), err,
@@ -181,8 +195,17 @@ class NativeDataInput(object):
     """``DataInput`` over a RecordSet: yields (step_i, PackedBatch), packing one batch ahead on a thread.
     ``index`` (optional) is the epoch's record order, e.g. ``shuffled_index(len(rs), seed)``."""
 
-    def __init__(self, recordset, batch_size, packer, index=None, prefetch=True):
+    _streams = 0
+
+    def __init__(self, recordset, batch_size, packer, index=None, prefetch=True, consumer=None):
+        """``consumer``: name of this batch stream's arena pool inside the packer.  Default: a pool of its
+        own per iterator; a trainer that builds one iterator per epoch passes a fixed name ("train", "eval")
+        so that the pinned arenas are allocated once."""
         self.rs, self.batch_size, self.packer = recordset, int(batch_size), packer
+        if consumer is None:
+            NativeDataInput._streams += 1
+            consumer = "stream%d" % NativeDataInput._streams
+        self.consumer = consumer
         n = len(recordset)
         self.index = np.arange(n, dtype=np.int64) if index is None else np.ascontiguousarray(index, np.int64)
         n = len(self.index)
@@ -194,7 +217,7 @@ class NativeDataInput(object):
         # calls (hipHostMalloc while the main thread captures a hipGraph invalidates the capture).
         for size in {min(self.batch_size, n), n % self.batch_size}:
             if size > 0:
-                packer._layout(size)
+                packer._layout(size, self.consumer)
 
     def __iter__(self):
         return self
@@ -207,7 +230,7 @@ class NativeDataInput(object):
 
         def work():
             try:
-                box["batch"] = self.packer.pack(self.rs, self._slice(i))
+                box["batch"] = self.packer.pack(self.rs, self._slice(i), consumer=self.consumer)
             except Exception as e:                     # re-raised on the consumer side
                 box["error"] = e
         t = threading.Thread(target=work, daemon=True)
@@ -218,7 +241,7 @@ class NativeDataInput(object):
         if self.i == self.epoch_size:
             raise StopIteration
         if not self.prefetch:
-            batch = self.packer.pack(self.rs, self._slice(self.i))
+            batch = self.packer.pack(self.rs, self._slice(self.i), consumer=self.consumer)
         else:
             if self._pending is None:
                 self._pending = self._start(self.i)

@@ -15,6 +15,9 @@ class MTAMRec_model(base_model):
         self.sess = sess
         self.now_bacth_data_size = "batch_size"          # (sic) placeholder name, reference :17
         self.num_units = self.FLAGS.num_units
+        if int(self.num_units) != 128:       # MTAM_D of include/mtam_hip.h; also checked by model_parameter.validate()
+            raise ValueError("num_units = %s: this build's kernels are compiled for num_units = 128 only"
+                             % (self.num_units,))
         self.num_heads = self.FLAGS.num_heads
         self.num_blocks = self.FLAGS.num_blocks
         self.dropout_rate = self.FLAGS.dropout           # unused on this path

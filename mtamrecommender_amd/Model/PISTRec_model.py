@@ -26,6 +26,8 @@ class PISTRec_model(base_model):
 
 
 class Time_Aware_self_Attention_model(PISTRec_model):
+    PATH_CLASS = SelfAttentionPath
+    ORACLE_NAME = "PISTRec"
 
     def build_model(self, seed=1234):
         D, L, NB = self.num_units, self.max_len, self.num_blocks
@@ -36,7 +38,7 @@ class Time_Aware_self_Attention_model(PISTRec_model):
         live = {s.name: values[s.name] for s in specs if s.trainable_grad}
         self.dead_variables = {s.name: values[s.name] for s in specs if not s.trainable_grad}
         device = getattr(self.sess, "device", "cuda:0")
-        self.path = SelfAttentionPath(self.embedding.tables(), live, L, self.num_heads, NB,
+        self.path = self.PATH_CLASS(self.embedding.tables(), live, L, self.num_heads, NB,
                                       self.FLAGS.regulation_rate, self.FLAGS.max_gradient_norm,
                                       tf_compat_global_norm=self.FLAGS.tf_compat_global_norm, device=device,
                                       optimizer=self.opt, score_dtype=getattr(self.FLAGS, "score_dtype", "f32"))

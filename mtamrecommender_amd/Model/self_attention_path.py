@@ -48,6 +48,7 @@ class _SABatch(_Batch):
 class SelfAttentionPath(TimeAwarePath):
     MODEL = "PISTRec"
     BATCH_CLASS = _SABatch
+    WITH_USER = 0        # 1: the loss is base_model.output() (user embedding in the L2 sum), see UserL2SelfAttentionPath
 
     # ----------------------------------------------------------------- forward
     def forward(self, bt, training=True):
@@ -55,7 +56,7 @@ class SelfAttentionPath(TimeAwarePath):
         d = D // H
         fd, T = bt.feed, self.tables
         ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
-                           fd["category_list"], fd["position_list"], fd["user_id"], B, L, 0,
+                           fd["category_list"], fd["position_list"], fd["user_id"], B, L, self.WITH_USER,
                            bt.ic, bt.pos, bt.user, bt.l2_partial,
                            # a training step's first kernel also clears its gradient accumulators
                            clear=(self.zero_prefix, bt.d_pred.view(-1)) if training else (), item16=self.item16)
@@ -133,6 +134,12 @@ class SelfAttentionPath(TimeAwarePath):
                                          M=2 * D, N=D, K=R, split_k=sr)])
         slot_part = part[self.nb_dense + self.nb_item:]
         ops.emb_scatter_add_bwd(bt.d_ic, d_out, bt.ic, bt.pos, bt.user, fd["item_list"], fd["category_list"],
-                                fd["position_list"], fd["user_id"], fd["seq_length"], B, L, self.reg, 0,
+                                fd["position_list"], fd["user_id"], fd["seq_length"], B, L, self.reg, self.WITH_USER,
                                 self.g_tab["item"], self.g_tab["category"], self.g_tab["position"],
                                 self.g_tab["user"], slot_part)
+
+
+class UserL2SelfAttentionPath(SelfAttentionPath):
+    """The same encoder under ``base_model.output()`` (Model/base_model.py:300-328): the L2 sum also takes the
+    user embedding rows, as ``Time_Aware_Self_Attention_Model`` does (Model/attention_baseline_models.py:47-65)."""
+    WITH_USER = 1

@@ -33,7 +33,8 @@ SHORT_LN = "ShortTermIntentEncoder/LayerNorm/"
 MTAM_VARIANTS = {
     # name: (gru cell, attention keys, layer_norm on the short-term intent, attention decoder)
     "MTAM": dict(gru="time", keys="x", short_ln=False, attention=True),                       # :61-92
-    "MTAM_only_time_aware_RNN": dict(gru="time", keys=None, short_ln=False, attention=False),  # :40-59
+    # type='T-SeqRec' = TimeAwareGRUCell_sigmoid (:51, Model/Modules/gru.py:70-71); experiment_type 'T_GRU'
+    "MTAM_only_time_aware_RNN": dict(gru="seqrec", keys=None, short_ln=False, attention=False),  # :40-59
     "MTAM_no_time_aware_rnn": dict(gru="plain", keys="x", short_ln=False, attention=True),     # :93-127
     "MTAM_via_T_GRU": dict(gru="time", keys="gru", short_ln=True, attention=True),             # :167-204
     "MTAM_via_rnn": dict(gru="plain", keys="gru", short_ln=True, attention=True),              # :206-238

@@ -80,11 +80,16 @@ class prepare_data_base(object):
         if os.path.exists(self.dataset_class_json):
             data_dic = json.load(open(self.dataset_class_json))
             data_dic["item_category"] = {int(k): v for k, v in data_dic["item_category"].items()}
-        else:
+        elif getattr(self.FLAGS, "allow_pickle_parameters", False):
             # a parameters.pkl written by the reference's own prepare step, loaded the way the reference
-            # loads it (:99-101); only use directories you produced yourself
+            # loads it (:99-101).  Explicit opt-in: unpickling executes what the file says
             with open(self.dataset_class_pkl, "rb") as f:
                 data_dic = pickle.load(f)
+        else:
+            raise FileNotFoundError(
+                "%s not found.  A directory prepared by the reference holds only parameters.pkl; set "
+                "FLAGS.allow_pickle_parameters = True to unpickle it (only for files you produced yourself), or "
+                "re-run the prepare step of this build, which writes parameters.json" % self.dataset_class_json)
         self.item_count = data_dic["item_count"]
         self.user_count = data_dic["user_count"]
         self.category_count = data_dic["category_count"]

@@ -142,6 +142,23 @@ class model_parameter(object):
                          'make_feed_dic_new per step')
         f.DEFINE_boolean('swallow_step_errors', False,
                          'log-and-continue on a failed step like train_process.py:369-371')
+        f.DEFINE_boolean('allow_pickle_parameters', False,
+                         'load a parameters.pkl written by the reference (Prepare/prepare_data_base.py:99-101) when no '
+                         'parameters.json sits next to it; unpickling executes what the file says, so opt in only for '
+                         'directories you produced yourself')
+
+    SUPPORTED_NUM_UNITS = 128       # MTAM_D of include/mtam_hip.h: every kernel is built for 512-byte rows
+
+    def validate(self):
+        """Reject flag values the HIP path has no kernels for -- here, not deep inside a launch."""
+        F = self.flags.FLAGS
+        if int(F.num_units) != self.SUPPORTED_NUM_UNITS:
+            raise ValueError("num_units = %s: this build's kernels are compiled for num_units = %d only "
+                             "(MTAM_D in include/mtam_hip.h; every reference preset uses 128)"
+                             % (F.num_units, self.SUPPORTED_NUM_UNITS))
+        if F.score_dtype not in ("f32", "bf16"):
+            raise ValueError("score_dtype must be 'f32' or 'bf16' (got %r)" % (F.score_dtype,))
+        return self
 
     def get_parameter(self, type):
         preset = _PRESETS.get(type)
@@ -152,7 +169,7 @@ class model_parameter(object):
             for key, value in merged.items():
                 setattr(self.flags.FLAGS, key, value)
         self.FLAGS = self.flags.FLAGS
-        return self
+        return self.validate()
 
     def parse_argv(self, argv):
         """CLI overrides (``--flag value``), as absl would apply them."""
@@ -172,4 +189,4 @@ class model_parameter(object):
         for name in values:
             setattr(self.flags.FLAGS, name, getattr(ns, name))
         self.FLAGS = self.flags.FLAGS
-        return self
+        return self.validate()

@@ -107,9 +107,13 @@ class Train_main_process(object):
                    "MTAM_hybird": family.MTAM_hybird}      # imported by the reference's trainer, reachable only here
         if self.FLAGS.experiment_type in members:
             self.model = members[self.FLAGS.experiment_type](self.FLAGS, self.emb, self.sess)
-        elif self.FLAGS.experiment_type in ("Time_Aware_Self_Attention_Model", "PISTRec"):
-            # train_process.py:209-210 dispatches Model/attention_baseline_models.py:47-65, the twin of
-            # PISTRec's Time_Aware_self_Attention_model (same graph; only the user L2 term differs)
+        elif self.FLAGS.experiment_type == "Time_Aware_Self_Attention_Model":
+            # train_process.py:209-210 -> Model/attention_baseline_models.py:47-65: PISTRec's encoder under
+            # base_model.output() (user embedding inside the L2 sum)
+            from .Model.attention_baseline_models import Time_Aware_Self_Attention_Model
+            self.model = Time_Aware_Self_Attention_Model(self.FLAGS, self.emb, self.sess)
+        elif self.FLAGS.experiment_type == "PISTRec":
+            # Model/PISTRec_model.py:38-74 (its own loss, no user L2); not dispatched by the reference's trainer
             from .Model.PISTRec_model import Time_Aware_self_Attention_model
             self.model = Time_Aware_self_Attention_model(self.FLAGS, self.emb, self.sess)
         else:
@@ -136,13 +140,15 @@ class Train_main_process(object):
             return DataInput(self.train_set, self.FLAGS.train_batch_size)
         from .DataHandle.native_input import NativeDataInput
         random.shuffle(self._order)          # the same permutation random.shuffle(train_set) would apply
-        return NativeDataInput(self._train_rs, self.FLAGS.train_batch_size, self._packer, index=self._order)
+        return NativeDataInput(self._train_rs, self.FLAGS.train_batch_size, self._packer, index=self._order,
+                               consumer="train")
 
     def _test_batches(self):
         if not self._native:
             return DataInput(self.test_set, self.FLAGS.test_batch_size)
         from .DataHandle.native_input import NativeDataInput
-        return NativeDataInput(self._test_rs, self.FLAGS.test_batch_size, self._packer)
+        # its own arena pool: an evaluation pass runs while the next TRAIN batch is already prefetched
+        return NativeDataInput(self._test_rs, self.FLAGS.test_batch_size, self._packer, consumer="eval")
 
     def eval_topk(self):
         per_batch = []

@@ -21,9 +21,19 @@ import math
 import numpy as np
 import torch
 
-from mtamrecommender_amd.Model.variables import (GRU_SCOPE, MTAM_VARIANTS, PLAIN_GRU_SCOPE, SHORT_LN, TIME_GATE,
-                                                TSR_SCOPE, head_ln_scope)
+# the family wiring and the TF scope strings are the oracle's OWN restatement (oracle/family.py): nothing is
+# imported from the product package, so a mis-wired member cannot pass by sharing a table with its checker
+try:
+    from .family import CELL_SCOPE, FAMILY, RUNNABLE, SHORT_LN_SCOPE, TIME_GATE_VARS
+except ImportError:          # imported as a top-level module
+    from family import CELL_SCOPE, FAMILY, RUNNABLE, SHORT_LN_SCOPE, TIME_GATE_VARS
 
+GRU_SCOPE, TSR_SCOPE, PLAIN_GRU_SCOPE = CELL_SCOPE["decay_new"], CELL_SCOPE["sigmoid"], CELL_SCOPE["gru"]
+SHORT_LN, TIME_GATE = SHORT_LN_SCOPE, TIME_GATE_VARS
+
+# Model/attention_baseline_models.py:47-65 (experiment_type 'Time_Aware_Self_Attention_Model', train_process.py:209-210):
+# PISTRec's encoder with base_model.output() as the loss.  Every other non-family name is PISTRec (:38-74)
+TASA = "Time_Aware_Self_Attention_Model"
 MASK_VALUE = float(-2 ** 32 + 1)      # time_aware_attention.py:392
 
 
@@ -232,12 +242,14 @@ def forward(model, w, feed, num_heads, num_blocks, regulation_rate, global_batch
     user, x, item, cat, pos = get_embedding(w, feed, score_dtype)
     sl = feed["seq_length"]
     B = x.shape[0]
-    if model in MTAM_VARIANTS:
-        # the MTAM family, Model/MTAMRec_model.py:40-238
-        cfg = MTAM_VARIANTS[model]
-        if cfg["gru"] == "time":
+    if model in FAMILY:
+        # the MTAM family, Model/MTAMRec_model.py:40-306, wired by the oracle's own table (oracle/family.py)
+        cfg = FAMILY[model]
+        if cfg["decoder"] == "plain":
+            raise NotImplementedError("%s: live dropout (SURVEY.md F8), no parity statement possible" % model)
+        if cfg["cell"] == "decay_new":
             hs = time_aware_gru(w, x, feed["timelast_list"], sl - 1)
-        elif cfg["gru"] == "seqrec":
+        elif cfg["cell"] == "sigmoid":
             hs = seqrec_gru(w, x, feed["timelast_list"], feed["timenow_list"], sl - 1)
         else:
             hs = plain_gru(w, x, sl - 1)
@@ -245,14 +257,14 @@ def forward(model, w, feed, num_heads, num_blocks, regulation_rate, global_batch
         if cfg["short_ln"]:
             short = layer_norm(short, w[SHORT_LN + "beta"], w[SHORT_LN + "gamma"])
         last = short
-        if cfg["attention"]:
-            user_history = hs if cfg["keys"] == "gru" else x
+        if cfg["decoder"] == "time_aware":
+            user_history = hs if cfg["keys"] == "rnn" else x
             last = vanilla_attention(w, user_history, short.unsqueeze(1), sl,
                                      feed["target_item_time"].unsqueeze(1), feed["time_list"], num_heads,
                                      num_blocks)
-        head = head_ln_scope(model)
+        head = cfg["head_ln"]
         pred = layer_norm(last, w[head + "beta"], w[head + "gamma"])
-        if cfg.get("head") == "concat":
+        if cfg["output"] == "output_concat":
             # MTAM_hybird (Model/MTAMRec_model.py:272) + base_model.output_concat (Model/base_model.py:340-346)
             pred = torch.matmul(torch.cat([short, pred], 1), w["output_w"])
         l2 = 0.5 * (item ** 2).sum() + 0.5 * (cat ** 2).sum() + 0.5 * (pos ** 2).sum() \
@@ -263,6 +275,10 @@ def forward(model, w, feed, num_heads, num_blocks, regulation_rate, global_batch
         pred = layer_norm(long_term, w["UserHistoryEncoder/LayerNorm/beta"],
                           w["UserHistoryEncoder/LayerNorm/gamma"])
         l2 = 0.5 * (item ** 2).sum() + 0.5 * (cat ** 2).sum() + 0.5 * (pos ** 2).sum()
+        if model == TASA:
+            # Model/attention_baseline_models.py:47-65: the same graph finished by base_model.output()
+            # (Model/base_model.py:300-307), whose L2 sum includes the user embedding
+            l2 = l2 + 0.5 * (user ** 2).sum()
     if score_dtype == "bf16":
         logits = torch.matmul(_bf16_straight_through(pred),
                               _bf16_straight_through(w["embedding_layer/item_score"]).t())
@@ -275,7 +291,7 @@ def forward(model, w, feed, num_heads, num_blocks, regulation_rate, global_batch
     loss = regulation_rate * l2 + ce.sum() / denom
     return dict(pred=pred, logits=logits, ce=ce, l2=l2, loss=loss, x=x,
                 user=user, item=item, cat=cat, pos=pos,
-                hs=hs if model in MTAM_VARIANTS else None)
+                hs=hs if model in FAMILY else None)
 
 
 def split_item_table(arrays, dtype, requires_grad=True):
@@ -333,7 +349,7 @@ def global_norm(grads, slot_sq, model, tf_compat=True):
         total += float((g.astype(np.float64) ** 2).sum())
     if tf_compat:
         total += slot_sq["item"] + slot_sq["item_dense"] + slot_sq["cat"] + slot_sq["pos"]
-        if model in MTAM_VARIANTS:
+        if model in FAMILY or model == TASA:
             total += slot_sq["user"]
     return math.sqrt(total)
 

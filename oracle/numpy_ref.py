@@ -6,7 +6,12 @@ restatement when one of the two mis-reads the reference.
 """
 import numpy as np
 
-from mtamrecommender_amd.Model.variables import GRU_SCOPE
+try:
+    from .family import CELL_SCOPE
+except ImportError:
+    from family import CELL_SCOPE
+
+GRU_SCOPE = CELL_SCOPE["decay_new"]
 
 
 def _sigmoid(x):

@@ -30,6 +30,9 @@ CASES = {
     # family members with kernels of their own (the T-SeqRec cell, the output_concat head)
     "mtam_with_t_seqrec_b6_l8_nb1_h2": ("MTAM_with_T_SeqRec", 6, 8, 128, 1, 2, 90, 7, 25, 14),
     "mtam_hybird_b6_l8_nb1_h1": ("MTAM_hybird", 6, 8, 128, 1, 1, 90, 7, 25, 15),
+    # experiment_type 'T_GRU': the T-SeqRec cell with no decoder (Model/MTAMRec_model.py:40-59; round 1 wired
+    # the decay_new cell here)
+    "mtam_only_time_aware_rnn_b6_l8": ("MTAM_only_time_aware_RNN", 6, 8, 128, 1, 1, 90, 7, 25, 16),
 }
 REG = 5e-5
 

@@ -38,7 +38,10 @@ def build(tmp_path, B, L, NB, H, items=300, cats=17, users=40, seed=5, id_dist="
     cat = SyntheticCatalog(items, cats, users, seed=seed)
     emb = Behavior_embedding_time_aware_attention(True, users, items, cats, L, seed=seed)
     from mtamrecommender_amd.Model import MTAMRec_model as family
-    cls = Time_Aware_self_Attention_model if model_name == "PISTRec" else getattr(family, model_name)
+    if model_name == "Time_Aware_Self_Attention_Model":
+        from mtamrecommender_amd.Model.attention_baseline_models import Time_Aware_Self_Attention_Model as cls
+    else:
+        cls = Time_Aware_self_Attention_model if model_name == "PISTRec" else getattr(family, model_name)
     model = cls(FLAGS, emb, Session("cuda:0"))
     # make every bias / scale non-trivial so that all gradient paths are exercised
     rng = np.random.default_rng(seed)
@@ -235,6 +238,31 @@ def test_pistrec_forward_and_gradients(hip_lib, tmp_path, B, L, NB, H):
             continue
         assert rel(got[name], g) < GRAD_TOL, name
     ref_norm = O.global_norm(grads, slot_sq, "PISTRec", True)
+    assert abs(float(p.scale[1]) - ref_norm) / ref_norm < 1e-4
+
+
+def test_time_aware_self_attention_model_has_the_user_l2_term(hip_lib, tmp_path):
+    """experiment_type 'Time_Aware_Self_Attention_Model' (Model/attention_baseline_models.py:47-65): PISTRec's encoder
+    under base_model.output() -- the loss and the clip norm include the user rows, the user table gets a gradient."""
+    import oracle.mtam_oracle as O
+    B, L, NB, H = 24, 50, 2, 2
+    model, FLAGS, records = build(tmp_path, B, L, NB, H, model_name="Time_Aware_Self_Attention_Model")
+    model.use_graph = False
+    p = model.path
+    arrays = {k: v.copy() for k, v in model.get_variables().items()}
+    feed = model.embedding.make_feed_dic_new(records)
+    out, grads, slot_sq = O.loss_and_grads(O.TASA, arrays, feed, H, NB, FLAGS.regulation_rate, torch.float64)
+    plain, _, _ = O.loss_and_grads("PISTRec", arrays, feed, H, NB, FLAGS.regulation_rate, torch.float64)
+    assert float(out["loss"].detach()) > float(plain["loss"].detach())
+    loss, _ = model.train(model.sess, records, 1e-3)
+    ref_loss = float(out["loss"].detach())
+    assert abs(loss - ref_loss) / abs(ref_loss) < 2e-5
+    got = p.grads_tf()
+    assert grads["embedding_layer/user"] is not None and np.any(got["embedding_layer/user"])
+    for name, g in grads.items():
+        if g is not None:
+            assert rel(got[name], g) < GRAD_TOL, name
+    ref_norm = O.global_norm(grads, slot_sq, O.TASA, True)
     assert abs(float(p.scale[1]) - ref_norm) / ref_norm < 1e-4
 
 

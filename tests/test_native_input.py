@@ -127,3 +127,38 @@ def test_native_data_input_slices_like_data_input(host):
     assert not np.array_equal(order, np.arange(37))
     seen = np.concatenate([b.index for _, b in NativeDataInput(rs, 8, packer, index=order)])
     assert np.array_equal(seen, order)
+
+
+def test_eval_between_two_train_batches_leaves_the_prefetched_train_batch_alone(host):
+    """Equal train / test batch sizes (round-1 advice): a >= 3-batch evaluation pass between two train batches must
+    not touch the arena that holds the already prefetched train batch -- every batch stream has its own pool."""
+    from mtamrecommender_amd.DataHandle.native_input import BatchPacker, NativeDataInput, RecordSet
+    from mtamrecommender_amd.Embedding.Behavior_embedding_time_aware_attention import \
+        Behavior_embedding_time_aware_attention
+    cat, records = _records(n=64, L=12)
+    emb = Behavior_embedding_time_aware_attention(True, cat.user_count, cat.item_count, cat.category_count, 12)
+    emb.init_placeholders()
+    rs = RecordSet.from_records(records)
+    packer = BatchPacker(12, emb)
+    train = NativeDataInput(rs, 8, packer, consumer="train")
+    step, first = next(train)                       # batch 2 is now being prefetched into the train pool
+    train._pending[0].join()
+    pending = train._pending[1]["batch"]
+    snapshot = pending.arena.clone()
+    seen = 0
+    for _, test_batch in NativeDataInput(rs, 8, packer, index=np.arange(63, -1, -1), consumer="eval"):
+        assert test_batch.arena.data_ptr() != pending.arena.data_ptr()
+        seen += 1
+    assert seen == 8
+    assert torch_equal(pending.arena, snapshot)
+    step2, second = next(train)
+    assert step2 == 2 and np.array_equal(second.field("item_list"),
+                                         emb.make_feed_dic_new(records[8:16])["item_list"])
+    # two anonymous iterators never share a pool either
+    a, b = NativeDataInput(rs, 8, packer), NativeDataInput(rs, 8, packer)
+    assert a.consumer != b.consumer and next(a)[1].arena.data_ptr() != next(b)[1].arena.data_ptr()
+
+
+def torch_equal(x, y):
+    import torch
+    return torch.equal(x, y)
