@@ -425,6 +425,21 @@ int mtam_topk(const float *scores, int ld, int rows, int V, int k,
 size_t mtam_topk_workspace_bytes(int rows, int V, int k);
 int mtam_topk_ws(const float *scores, int ld, int rows, int V, int k, int32_t *idx_out, float *val_out,
                  void *workspace, void *stream);
+/* The same result WITHOUT a stored [rows, V] score matrix: the evaluation sess.run (Model/base_model.py:194-202)
+ * at catalog sizes where predict_behavior_emb . item_table^T does not fit (25.6 GB at 128 x 50 M).  The caller scores
+ * the catalog slab by slab (mtam_gemm_f32 / mtam_score16_logits on a row range of the item table: each score is the
+ * same k-ordered fmaf chain as in the one-piece product) into a [rows, ld] scratch and hands every slab to
+ * mtam_topk_stream_slab: columns [col0, col0 + width) of the full matrix, col0 a multiple of MTAM_TOPK_STREAM_SEG.
+ * Every (row, segment of MTAM_TOPK_STREAM_SEG columns) keeps its k best in `workspace`
+ * (mtam_topk_stream_workspace_bytes(rows, V, k) bytes, any contents before the first slab; every segment of
+ * [0, V) must be handed in once); mtam_topk_stream_finish then writes the rows' top k.  Lists are identical to
+ * mtam_topk on the stored matrix, ties across slab and segment boundaries included. */
+#define MTAM_TOPK_STREAM_SEG 65536
+int mtam_topk_stream_segments(int V);
+size_t mtam_topk_stream_workspace_bytes(int rows, int V, int k);
+int mtam_topk_stream_slab(const float *slab_scores, int ld, int rows, int col0, int width, int V, int k,
+                          void *workspace, void *stream);
+int mtam_topk_stream_finish(void *workspace, int rows, int V, int k, int32_t *idx_out, float *val_out, void *stream);
 
 /* ------------------------------------------------ clip_by_global_norm + Adam
  * tf.clip_by_global_norm + AdamOptimizer.apply_gradients
@@ -449,6 +464,14 @@ int mtam_sqnorm_blocks(size_t n);
 int mtam_sqnorm_partial(const float *g, size_t n, float *partial, void *stream);
 int mtam_clip_scale(const float *partials, int n_partials, float clip_norm, float *scale,
                     const float *lr, float *adam_state, void *stream);
+/* Data-parallel training with the item table's gradient reduce-scattered by row range (the reference
+ * has no multi-GPU path): every rank sums the squares of the gradient elements it OWNS,
+ *   mtam_partials_sum: out[0] (+)= weight * sum(partials[0 .. n))   in double (accumulate != 0: added to out[0]),
+ * the per-rank doubles are all-reduced by the caller (RCCL), and
+ *   mtam_clip_scale_sq: mtam_clip_scale with norm = sqrt(sq_total[0] + .. + sq_total[n - 1]),  n <= 64. */
+int mtam_partials_sum(const float *partials, int n, float weight, double *out, int accumulate, void *stream);
+int mtam_clip_scale_sq(const double *sq_total, int n, float clip_norm, float *scale, const float *lr,
+                       float *adam_state, void *stream);
 /* mtam_sqnorm_partial(g -> partials[offset...]) and mtam_clip_scale over partials[0 .. n_total) in ONE
  * launch (the last workgroup to finish does the reduction).  ticket: one device word, zero on the
  * first call, reset by the kernel.  With `loss` given the same workgroup also does mtam_loss_reduce

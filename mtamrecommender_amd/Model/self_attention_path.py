@@ -51,7 +51,7 @@ class SelfAttentionPath(TimeAwarePath):
     WITH_USER = 0        # 1: the loss is base_model.output() (user embedding in the L2 sum), see UserL2SelfAttentionPath
 
     # ----------------------------------------------------------------- forward
-    def forward(self, bt, training=True):
+    def forward(self, bt, training=True, score=True):
         B, R, L, NB, H = bt.B, bt.R, self.L, self.NB, self.H
         d = D // H
         fd, T = bt.feed, self.tables
@@ -82,7 +82,8 @@ class SelfAttentionPath(TimeAwarePath):
         ops.seq_row_gather(bt.enc[NB], fd["seq_length"], -1, B, L, bt.long)
         hl = self.seg("head/ln")
         ops.layer_norm_fwd(bt.long, hl[0], hl[1], 1e-12, B, bt.pred, bt.ln_save if training else None)
-        self.score_forward(bt, training)
+        if score:
+            self.score_forward(bt, training)
 
     # ---------------------------------------------------------------- backward
     def backward(self, bt):

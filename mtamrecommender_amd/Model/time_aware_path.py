@@ -101,9 +101,12 @@ class _Batch(object):
         # logits rows start on 16-byte boundaries (row stride = V rounded up to 4 floats) so that the
         # transposed read of d_logits in the item-gradient GEMM takes the vector-load path; `logits` is the
         # [B, V] view of that storage
+        # Allocated on first use (the `logits_store` property): only the stored-logits fp32 training path and
+        # the stored form of evaluation touch it -- 5.1 GB at 128 x 10 M, 25.6 GB at 128 x 50 M, 410 GB at the
+        # preset test batch of 2,048 x 50 M, which logits-free training and slab-wise evaluation never need
         self.ld_logits = (V + 3) // 4 * 4
-        self.logits_store = f(B, self.ld_logits)
-        self.logits = self.logits_store[:, :V]
+        self._path_V, self._dev, self._logits_store = V, dev, None
+        self.eval_slab = None        # [B, slab] score scratch of the slab-wise evaluation
         self.lse, self.ce = f(B), f(B)
         if path.logits_free32:
             self.s32_partial = f(ops.score32_partials(B, V))
@@ -137,6 +140,16 @@ class _Batch(object):
         self.norm_partial = torch.zeros(path.nb_all + self.n_slot, dtype=torch.float32, device=dev)
         self.topk_idx = torch.zeros((B, 50), dtype=torch.int32, device=dev)
         self.topk_ws = None         # candidate scratch of the two-level top-K (long rows only)
+
+    @property
+    def logits_store(self):
+        if self._logits_store is None:
+            self._logits_store = torch.zeros((self.B, self.ld_logits), dtype=torch.float32, device=self._dev)
+        return self._logits_store
+
+    @property
+    def logits(self):
+        return self.logits_store[:, :self._path_V]
 
     def _view(self, arena, name):
         o, n, shape, dt = self.offsets[name]
@@ -211,8 +224,12 @@ class TimeAwarePath(object):
         # B=128: 3,709 rows 0.3012 vs 0.3049 ms, 8,003 rows 0.3128 vs 0.3095, 30,003 rows 0.379 vs 0.352 --
         # every 32-row slab flushes a [128, 128] share of d_pred by atomics, which stops paying beyond a few
         # thousand rows.  MTAM_FUSED_SCORE_MAX_ROWS overrides the limit (0 = never)
+        # Large catalogs (>= MTAM_FUSED_SCORE_MIN_LARGE_ROWS, default 262,144) never materialise [B, V] either
+        # (SURVEY.md K9): the same two kernels, each workgroup owning a contiguous range of slabs with its
+        # share of d_pred in accumulator registers for the whole range (one flush of <= 512 x 64 KB)
         self.logits_free32 = score_dtype == "f32" and \
-            self.item_rows <= int(os.environ.get("MTAM_FUSED_SCORE_MAX_ROWS", "4096"))
+            (self.item_rows <= int(os.environ.get("MTAM_FUSED_SCORE_MAX_ROWS", "4096")) or
+             self.item_rows >= int(os.environ.get("MTAM_FUSED_SCORE_MIN_LARGE_ROWS", "262144")))
         if self.logits_free32:
             self.nb_item = ops.score32_sq_partials(self.item_rows)
         self.item16 = None
@@ -311,8 +328,9 @@ class TimeAwarePath(object):
         ops.gemm(bt.logits_store, self.tables["item"], bt.d_pred, epilogue=ops.EPI_ATOMIC, split_k=split_v, K=V)
 
     # ----------------------------------------------------------------- forward
-    def forward(self, bt, training=True):
-        """Model/MTAMRec_model.py:40-238 (the member is chosen by ``self.cfg``)."""
+    def forward(self, bt, training=True, score=True):
+        """Model/MTAMRec_model.py:40-238 (the member is chosen by ``self.cfg``).  score=False stops at
+        predict_behavior_emb (slab-wise evaluation scores the catalog itself)."""
         B, R, L, NB, H = bt.B, bt.R, self.L, self.NB, self.H
         fd, T, cfg = bt.feed, self.tables, self.cfg
         ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
@@ -376,7 +394,8 @@ class TimeAwarePath(object):
         if bt.concat_head:
             W = self.seg("head/output_w")
             ops.gemm_dual(bt.short, W[:D], bt.ln_out, W[D:], bt.pred, trans_b=False)
-        self.score_forward(bt, training)
+        if score:
+            self.score_forward(bt, training)
 
     def loss_and_logit_grad(self, bt):
         if self.score_dtype == "bf16" or self.logits_free32:
@@ -533,13 +552,50 @@ class TimeAwarePath(object):
             self.allreduce_fn(self, bt)
         self.clip_and_apply(bt)
 
-    def eval_kernels(self, bt, k=50):
-        self.forward(bt, training=False)
-        nbytes = ops.topk_workspace_bytes(bt.B, self.item_rows, k)
-        if nbytes and (bt.topk_ws is None or bt.topk_ws.numel() * 4 < nbytes):
+    # evaluation scores the catalog in one piece while the [B, V] matrix is small; beyond this many bytes it goes
+    # slab by slab through a bounded scratch and keeps only per-segment top-k candidates
+    EVAL_STORED_MAX_BYTES = int(os.environ.get("MTAM_EVAL_STORED_MAX_BYTES", str(1 << 30)))
+    EVAL_SLAB_BYTES = int(os.environ.get("MTAM_EVAL_SLAB_BYTES", str(1 << 30)))
+
+    def eval_slab_width(self, B):
+        seg = ops.TOPK_STREAM_SEG
+        w = max(seg, self.EVAL_SLAB_BYTES // (4 * B) // seg * seg)
+        return min(w, (self.item_rows + seg - 1) // seg * seg)
+
+    def eval_kernels(self, bt, k=50, stored=None):
+        """Forward + top-k of predict_behavior_emb . item_table^T (Model/base_model.py:194-202).
+        stored=True keeps the whole [B, V] logits (``bt.logits``); False scores slab by slab and never holds
+        more than EVAL_SLAB_BYTES of scores; None picks by size.  Both give identical lists."""
+        V = self.item_rows
+        if stored is None:
+            stored = bt.B * bt.ld_logits * 4 <= self.EVAL_STORED_MAX_BYTES
+        if stored:
+            self.forward(bt, training=False)
+            nbytes = ops.topk_workspace_bytes(bt.B, V, k)
+            if nbytes and (bt.topk_ws is None or bt.topk_ws.numel() * 4 < nbytes):
+                bt.topk_ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            ops.topk(bt.logits_store, bt.ld_logits, bt.B, V, k, bt.topk_idx,
+                     workspace=bt.topk_ws if nbytes else None)
+            return
+        self.forward(bt, training=False, score=False)
+        W = self.eval_slab_width(bt.B)
+        if bt.eval_slab is None or bt.eval_slab.shape[1] != W:
+            bt.eval_slab = torch.empty((bt.B, W), dtype=torch.float32, device=self.device)
+        nbytes = ops.topk_stream_workspace_bytes(bt.B, V, k)
+        if bt.topk_ws is None or bt.topk_ws.numel() * 4 < nbytes:
             bt.topk_ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
-        ops.topk(bt.logits_store, bt.ld_logits, bt.B, self.item_rows, k, bt.topk_idx,
-                 workspace=bt.topk_ws if nbytes else None)
+        if self.score_dtype == "bf16":
+            ops.f32_to_bf16(bt.pred.view(-1), bt.pred16.view(-1))
+        for col0 in range(0, V, W):
+            width = min(W, V - col0)
+            if self.score_dtype == "f32":
+                # rows [col0, col0 + width) of the item table: every score is the same k-ordered fmaf chain
+                # as in the one-piece product
+                ops.gemm(bt.pred, self.tables["item"][col0:col0 + width], bt.eval_slab, trans_b=True, ldc=W)
+            else:
+                ops.score16_logits(self.item16[col0:col0 + width], bt.pred16, bt.B, width, bt.eval_slab, W)
+            ops.topk_stream_slab(bt.eval_slab, W, bt.B, col0, width, V, k, bt.topk_ws)
+        ops.topk_stream_finish(bt.topk_ws, bt.B, V, k, bt.topk_idx)
 
     # ------------------------------------------------------- weights in / out
     def dense_tf(self):

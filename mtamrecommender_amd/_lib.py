@@ -63,6 +63,12 @@ SIGNATURES = {
     "mtam_topk": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     "mtam_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mtam_topk_ws": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "mtam_partials_sum": (c_int, [P, c_int, c_float, P, c_int, P]),
+    "mtam_clip_scale_sq": (c_int, [P, c_int, c_float, P, P, P, P]),
+    "mtam_topk_stream_segments": (c_int, [c_int]),
+    "mtam_topk_stream_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "mtam_topk_stream_slab": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "mtam_topk_stream_finish": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "mtam_f32_to_bf16": (c_int, [P, c_size_t, P, c_size_t, P]),
     "mtam_score16_batch_pad": (c_int, [c_int]),
     "mtam_score16_partials": (c_int, [c_int, c_int]),

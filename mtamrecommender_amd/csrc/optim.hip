@@ -57,6 +57,40 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(const float *__restrict
   }
 }
 
+// Data-parallel form with a row-sharded item table (data_parallel.py): every rank sums the squares of what it
+// OWNS into one double, the doubles are all-reduced, and the clip scale comes from the total.
+__global__ __launch_bounds__(256) void partials_sum_kernel(const float *__restrict__ partials, int n, float weight,
+                                                           double *__restrict__ out, int accumulate) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (double)weight * ((red[0] + red[1]) + (red[2] + red[3]));
+    out[0] = accumulate ? out[0] + t : t;
+  }
+}
+
+__global__ void clip_scale_sq_kernel(const double *__restrict__ sq, int n, float clip, float *__restrict__ scale,
+                                     const float *__restrict__ lr, float *__restrict__ adam_state) {
+  if (threadIdx.x != 0) return;
+  double t = 0.0;
+  for (int i = 0; i < n; ++i) t += sq[i];
+  const float norm = sqrtf((float)t);
+  scale[0] = clip * fminf(1.0f / norm, 1.0f / clip);
+  scale[1] = norm;
+  if (adam_state) {
+    const float b1 = adam_state[1], b2 = adam_state[2];
+    const float b1p = adam_state[4], b2p = adam_state[5];
+    adam_state[0] = lr[0] * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    adam_state[4] = b1p * b1;
+    adam_state[5] = b2p * b2;
+  }
+}
+
 // sqnorm + clip_scale in one launch: every workgroup writes its partial; the last one to arrive
 // (agent-scope ticket; partials moved by sc1 stores / sc1 loads) sums ALL partials and does what
 // clip_scale_kernel does.  `ticket` must be zero on entry and is left zero.
@@ -321,6 +355,25 @@ extern "C" int mtam_clip_scale(const float *partials, int n_partials, float clip
   hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partials,
                      n_partials, clip_norm, scale, lr, adam_state);
   MTAM_CHECK_LAUNCH("clip_scale");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_partials_sum(const float *partials, int n, float weight, double *out, int accumulate,
+                                 void *stream) {
+  MTAM_CHECK_ARG(partials && out && n > 0, "partials_sum: bad arguments");
+  hipLaunchKernelGGL(partials_sum_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), partials, n, weight,
+                     out, accumulate);
+  MTAM_CHECK_LAUNCH("partials_sum");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_clip_scale_sq(const double *sq_total, int n, float clip_norm, float *scale, const float *lr,
+                                  float *adam_state, void *stream) {
+  MTAM_CHECK_ARG(sq_total && scale && n > 0 && n <= 64 && clip_norm > 0.f, "clip_scale_sq: bad arguments");
+  MTAM_CHECK_ARG((lr == nullptr) == (adam_state == nullptr), "clip_scale_sq: lr and adam_state go together");
+  hipLaunchKernelGGL(clip_scale_sq_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), sq_total, n,
+                     clip_norm, scale, lr, adam_state);
+  MTAM_CHECK_LAUNCH("clip_scale_sq");
   return MTAM_OK;
 }
 

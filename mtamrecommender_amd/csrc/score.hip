@@ -272,7 +272,8 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
 // wave per SIMD: 80 ms for 128 rows of 50 M scores.
 __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ scores, long ld, int V_row, int k,
                                                    int32_t *__restrict__ idx_out, float *__restrict__ val_out,
-                                                   int seg, const int32_t *__restrict__ idx_map, float fill) {
+                                                   int seg, const int32_t *__restrict__ idx_map, float fill,
+                                                   int out_segs, int out_seg0, int idx_base) {
   __shared__ uint32_t hist[2048];
   __shared__ uint32_t scan[256];
   __shared__ uint32_t sel_bin, sel_above;
@@ -286,7 +287,9 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ sco
   const int seg0 = blockIdx.y * seg;                       // first element of this workgroup's segment
   const int V = min(seg, V_row - seg0);
   const float *s = scores + (size_t)row * ld + seg0;
-  const size_t out_row = (size_t)row * gridDim.y + blockIdx.y;
+  // candidate slot of this (row, segment): rows keep `out_segs` slots (0: gridDim.y), this launch fills the
+  // slots from out_seg0 on; reported indices are offset by idx_base (a slab of a longer row)
+  const size_t out_row = (size_t)row * (out_segs ? out_segs : gridDim.y) + out_seg0 + blockIdx.y;
   const int kk = max(0, min(k, V));
   // f(index, value) over the row: independent loads in flight per thread and trip -- four 16-byte
   // loads when the row starts on a 16-byte boundary (the model pads the logits row stride), else eight
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ sco
       const uint32_t key = (uint32_t)(item >> 32);
       const uint32_t idx = 0xffffffffu - (uint32_t)(item & 0xffffffffu);
       int32_t out = -1;
-      if (lane < kk) out = idx_map ? idx_map[(size_t)row * ld + idx] : (int32_t)idx + seg0;
+      if (lane < kk) out = idx_map ? idx_map[(size_t)row * ld + idx] : (int32_t)idx + seg0 + idx_base;
       idx_out[out_row * k + lane] = out;
       if (val_out) val_out[out_row * k + lane] = (lane < kk) ? key_to_float(key) : fill;
     }
@@ -541,17 +544,63 @@ extern "C" int mtam_topk_ws(const float *scores, int ld, int rows, int V, int k,
   const int seg = topk_seg_len(V), S = (V + seg - 1) / seg;
   if (!workspace || topk_segments(V) == 1 || S == 1) {
     hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(256), 0, st, scores, (long)ld, V, k, idx_out, val_out, V,
-                       static_cast<const int32_t *>(nullptr), 0.f);
+                       static_cast<const int32_t *>(nullptr), 0.f, 0, 0, 0);
   } else {
     MTAM_CHECK_ARG(rows <= 65535 * 1 && S <= 65535, "topk: too many segments");
     float *cand_val = static_cast<float *>(workspace);
     int32_t *cand_idx = reinterpret_cast<int32_t *>(cand_val + (size_t)rows * S * k);
     hipLaunchKernelGGL(topk_kernel, dim3(rows, S), dim3(256), 0, st, scores, (long)ld, V, k, cand_idx, cand_val, seg,
-                       static_cast<const int32_t *>(nullptr), -INFINITY);
+                       static_cast<const int32_t *>(nullptr), -INFINITY, 0, 0, 0);
     hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(256), 0, st, cand_val, (long)S * k, S * k, k, idx_out, val_out,
-                       S * k, cand_idx, 0.f);
+                       S * k, cand_idx, 0.f, 0, 0, 0);
   }
   MTAM_CHECK_LAUNCH("topk");
+  return MTAM_OK;
+}
+
+// ---- top-K over a catalog that is scored slab by slab (evaluation without stored [rows, V] logits) ----------
+// A slab = columns [col0, col0 + width) of the score matrix, held in a [rows, ld] scratch.  Each slab is cut into
+// segments of MTAM_TOPK_STREAM_SEG columns; every (row, segment) keeps its k best as candidates in
+// `workspace` (values, then indices: rows x total_segments x k each); mtam_topk_stream_finish picks the final
+// k per row.  Slabs must start on a multiple of the segment length, so that a candidate's slot order is its
+// global index order -- the tie rule (equal values: lower index first) then holds across slab and segment
+// boundaries exactly as in mtam_topk.
+static const int kStreamSeg = MTAM_TOPK_STREAM_SEG;
+extern "C" int mtam_topk_stream_segments(int V) { return V <= 0 ? 0 : (V + kStreamSeg - 1) / kStreamSeg; }
+extern "C" size_t mtam_topk_stream_workspace_bytes(int rows, int V, int k) {
+  if (rows <= 0 || V <= 0 || k <= 0) return 0;
+  return (size_t)rows * mtam_topk_stream_segments(V) * k * 8;
+}
+
+extern "C" int mtam_topk_stream_slab(const float *slab_scores, int ld, int rows, int col0, int width, int V, int k,
+                                     void *workspace, void *stream) {
+  MTAM_CHECK_ARG(slab_scores && workspace && rows > 0 && rows <= 65535, "topk_stream_slab: bad arguments");
+  MTAM_CHECK_ARG(k >= 1 && k <= 64, "topk_stream_slab: k must be in [1, 64] (got %d)", k);
+  MTAM_CHECK_ARG(col0 >= 0 && width > 0 && ld >= width && (long)col0 + width <= V && col0 % kStreamSeg == 0,
+                 "topk_stream_slab: slab [%d, +%d) of %d columns must start on a multiple of %d", col0, width, V,
+                 kStreamSeg);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int S = mtam_topk_stream_segments(V), nseg = (width + kStreamSeg - 1) / kStreamSeg;
+  float *cand_val = static_cast<float *>(workspace);
+  int32_t *cand_idx = reinterpret_cast<int32_t *>(cand_val + (size_t)rows * S * k);
+  hipLaunchKernelGGL(topk_kernel, dim3(rows, nseg), dim3(256), 0, st, slab_scores, (long)ld, width, k, cand_idx,
+                     cand_val, kStreamSeg, static_cast<const int32_t *>(nullptr), -INFINITY, S, col0 / kStreamSeg,
+                     col0);
+  MTAM_CHECK_LAUNCH("topk_stream_slab");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_topk_stream_finish(void *workspace, int rows, int V, int k, int32_t *idx_out, float *val_out,
+                                       void *stream) {
+  MTAM_CHECK_ARG(workspace && idx_out && rows > 0 && V > 0, "topk_stream_finish: bad arguments");
+  MTAM_CHECK_ARG(k >= 1 && k <= 64, "topk_stream_finish: k must be in [1, 64] (got %d)", k);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int S = mtam_topk_stream_segments(V);
+  float *cand_val = static_cast<float *>(workspace);
+  int32_t *cand_idx = reinterpret_cast<int32_t *>(cand_val + (size_t)rows * S * k);
+  hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(256), 0, st, cand_val, (long)S * k, S * k, k, idx_out, val_out,
+                     S * k, cand_idx, 0.f, 0, 0, 0);
+  MTAM_CHECK_LAUNCH("topk_stream_finish");
   return MTAM_OK;
 }
 

@@ -15,6 +15,7 @@
 // independent accumulator chains per tile: a dependent MFMA issues every ~84 cycles, an independent one
 // every 64).  Evaluation keeps the stored-logits GEMM (its k-ordered fmaf chain is the ranking contract).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -281,7 +282,19 @@ __global__ __launch_bounds__(256) void score32_bwd_kernel(BwdArgs p) {
 }
 
 int slabs_of(int V) { return (V + SLAB - 1) / SLAB; }
-int chunks_of(int V) { return max(1, min(slabs_of(V), 2048)); }
+// Workgroups per batch tile: each owns a contiguous range of slabs and flushes its [128, 128] share of d_pred
+// ONCE, by atomics (64 KB each at the ~1.3 TB/s float-atomic rate: 2,048 workgroups = 100 us, 512 = 25 us).
+// The backward kernel holds 336 registers per lane = one workgroup per CU, so 512 ranges are two rounds over
+// the 256 CUs.  MTAM_SCORE32_MAX_WGS overrides (read once).
+int max_wgs() {
+  static const int v = [] {
+    const char *e = getenv("MTAM_SCORE32_MAX_WGS");
+    const int n = e ? atoi(e) : 512;
+    return n > 0 ? n : 512;
+  }();
+  return v;
+}
+int chunks_of(int V) { return max(1, min(slabs_of(V), max_wgs())); }
 int slabs_per_wg_of(int V) { return (slabs_of(V) + chunks_of(V) - 1) / chunks_of(V); }
 int grid_of(int V) { return (slabs_of(V) + slabs_per_wg_of(V) - 1) / slabs_per_wg_of(V); }
 

@@ -283,6 +283,26 @@ def topk(scores, ld, rows, V, k, idx_out, val_out=None, workspace=None):
                "mtam_topk")
 
 
+TOPK_STREAM_SEG = 65536        # MTAM_TOPK_STREAM_SEG
+
+
+def topk_stream_workspace_bytes(rows, V, k):
+    return _lib.load().mtam_topk_stream_workspace_bytes(rows, V, k)
+
+
+def topk_stream_slab(slab_scores, ld, rows, col0, width, V, k, workspace):
+    """Candidates of columns [col0, col0 + width) of a [rows, V] score matrix that is never stored whole."""
+    lib = _lib.load()
+    _lib.check(lib.mtam_topk_stream_slab(_p(slab_scores), ld, rows, col0, width, V, k, _p(workspace), _stream()),
+               "mtam_topk_stream_slab")
+
+
+def topk_stream_finish(workspace, rows, V, k, idx_out, val_out=None):
+    lib = _lib.load()
+    _lib.check(lib.mtam_topk_stream_finish(_p(workspace), rows, V, k, _pi(idx_out), _p(val_out), _stream()),
+               "mtam_topk_stream_finish")
+
+
 # ---- bf16 scoring (csrc/score16.hip): bf16 bit patterns travel as torch.bfloat16 tensors
 def _pb(t):
     return _p(t, torch.bfloat16)
@@ -365,6 +385,19 @@ def clip_scale(partials, n_partials, clip_norm, scale, lr=None, adam_state=None)
     lib = _lib.load()
     _lib.check(lib.mtam_clip_scale(_p(partials), n_partials, float(clip_norm), _p(scale), _p(lr),
                                    _p(adam_state), _stream()), "mtam_clip_scale")
+
+
+def partials_sum(partials, n, weight, out, accumulate=False):
+    """out[0] (+)= weight * sum(partials[:n]) in float64 (one rank's share of the squared gradient norm)."""
+    lib = _lib.load()
+    _lib.check(lib.mtam_partials_sum(_p(partials), n, float(weight), _p(out, torch.float64), int(accumulate),
+                                     _stream()), "mtam_partials_sum")
+
+
+def clip_scale_sq(sq_total, n, clip_norm, scale, lr=None, adam_state=None):
+    lib = _lib.load()
+    _lib.check(lib.mtam_clip_scale_sq(_p(sq_total, torch.float64), n, float(clip_norm), _p(scale), _p(lr),
+                                      _p(adam_state), _stream()), "mtam_clip_scale_sq")
 
 
 def sqnorm_clip_scale(g, n, partials, offset, n_total, clip_norm, scale, lr, adam_state, ticket,

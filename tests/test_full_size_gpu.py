@@ -62,7 +62,13 @@ def test_c3_pistrec_1m_items(hip_lib, tmp_path):
     chain = co.score_fma(pred[rows], arrays["embedding_layer/item"])
     assert np.array_equal(logits[rows], chain)
     assert np.array_equal(top[rows], O.top_k(chain, 50))
+    # evaluation without stored logits (slab-wise scoring + per-segment candidates): the same lists
+    p.EVAL_SLAB_BYTES = 128 << 20                        # 4 slabs of 262,144 columns
+    p.eval_kernels(bt, 50, stored=False)
+    assert np.array_equal(bt.topk_idx.cpu().numpy(), top)
 
+    # training at this size keeps no [B, V] logits (csrc/score32.hip)
+    assert p.logits_free32
     loss, summary = model.train(model.sess, records, 1e-3)
     ref_loss = float(out["loss"].detach())
     assert abs(loss - ref_loss) / abs(ref_loss) < 1e-4
@@ -87,7 +93,7 @@ def test_c4_mtam_10m_items_properties(hip_lib, tmp_path):
     bt = p.load_feed(feed)
 
     # ---- forward: gathered rows are the table rows, bit for bit
-    p.eval_kernels(bt, 50)
+    p.eval_kernels(bt, 50, stored=True)
     item_ids = torch.from_numpy(feed["item_list"].astype(np.int64)).cuda().view(-1)
     cat_ids = torch.from_numpy(feed["category_list"].astype(np.int64)).cuda().view(-1)
     assert torch.equal(bt.ic[:, :128], p.tables["item"][item_ids])
@@ -103,21 +109,46 @@ def test_c4_mtam_10m_items_properties(hip_lib, tmp_path):
     kth = vals[:, -1:]
     assert bool(((bt.logits > kth).sum(1) <= 49).all())          # nothing outside the list beats its last entry
     assert bool(((bt.logits >= kth).sum(1) >= 50).all())
+    # ---- evaluation without stored logits (what the model runs at this size): identical lists
+    stored_top = bt.topk_idx.clone()
+    assert bt.B * bt.ld_logits * 4 > p.EVAL_STORED_MAX_BYTES      # the default route here is the slab-wise one
+    p.eval_kernels(bt, 50)
+    assert torch.equal(bt.topk_idx, stored_top)
 
-    # ---- softmax CE: gradient rows sum to zero, loss = mean(lse - target logit)
-    logits = bt.logits.clone()
-    p.loss_and_logit_grad(bt)
-    torch.cuda.synchronize()
-    row_sum = bt.logits.double().sum(1)
-    assert float(row_sum.abs().max()) < 1e-6
+    # ---- logits-free training kernels (csrc/score32.hip) against the stored evaluation logits: lse, cross
+    # entropy, d_pred, and dE on sampled rows equal float64 products of G = (softmax - onehot) / B
+    assert p.logits_free32
+    logits = bt.logits
     tgt = torch.from_numpy(feed["target_item_id"].astype(np.int64)).cuda()
     lse = torch.logsumexp(logits.double(), dim=1)
     ce = lse - logits.double().gather(1, tgt[:, None])[:, 0]
+    p.forward_backward_kernels(bt)
+    torch.cuda.synchronize()
+    assert float((bt.lse.double() - lse).abs().max()) < 1e-5 * float(lse.abs().max())
     assert float((bt.ce.double() - ce).abs().max()) < 1e-4
-    # d_logits = (softmax - onehot) / B: its minimum sits at the target and equals (p_target - 1) / B
-    d = bt.logits.double()
-    p_t = torch.exp(logits.double().gather(1, tgt[:, None])[:, 0] - lse)
-    assert float((d.gather(1, tgt[:, None])[:, 0] - (p_t - 1.0) / B).abs().max()) < 1e-8
+    cols = torch.cat([torch.randint(0, V, (4096,), device="cuda"), tgt, torch.tensor([0, V - 1], device="cuda")])
+    G = torch.exp(logits[:, cols].double() - lse[:, None]) / B
+    G -= (cols[None, :] == tgt[:, None]).double() / B
+    ref_dE = G.T @ bt.pred.double()
+    untouched = ~torch.isin(cols, item_ids)                  # history rows also receive the gather's gradient
+    err = (p.g_tab["item"][cols].double() - ref_dE).abs()[untouched].max()
+    assert float(err) < 2e-5 * float(ref_dE.abs().max())
+    # softmax rows sum to one: sum_v G[b, v] = 0, so d_pred = G E has the norm of a float64 chunked product
+    ref_dpred = torch.zeros((B, 128), dtype=torch.float64, device="cuda")
+    for c in range(0, V, 1 << 20):
+        hi = min(V, c + (1 << 20))
+        Gc = torch.exp(logits[:, c:hi].double() - lse[:, None]) / B
+        inside = (tgt >= c) & (tgt < hi)
+        Gc[torch.nonzero(inside)[:, 0], (tgt[inside] - c)] -= 1.0 / B
+        ref_dpred += Gc @ p.tables["item"][c:hi].double()
+    # d_pred is what the head layer_norm's backward consumed: bt.d_pred still holds it (accumulated once)
+    assert float((bt.d_pred.double() - ref_dpred).abs().max()) < 2e-5 * float(ref_dpred.abs().max())
+    part = float(bt.norm_partial[p.nb_dense:p.nb_dense + p.nb_item].double().sum())
+    tot = sum(float((p.g_tab["item"][c * V // 8:(c + 1) * V // 8].double() ** 2).sum()) for c in range(8))
+    touched_sq = float((p.g_tab["item"][item_ids.unique()].double() ** 2).sum())
+    assert abs(part - tot) <= 1e-4 * tot + 2.0 * touched_sq
+    bt._logits_store = None                                  # drop the 5 GB of stored logits before the steps
+    logits = None
 
     # ---- a training step: a row no sample touches moves exactly as dense Adam on the scoring gradient
     # alone says; touched rows move; the loss falls over a few steps
@@ -162,7 +193,10 @@ def test_c5_shape_fp32_50m_items_l200(hip_lib, tmp_path):
     records = make_records(cat, B, L, seed=6)
     feed = emb.make_feed_dic_new(records)
     bt = p.load_feed(feed)
-    p.eval_kernels(bt, 50)
+    p.eval_kernels(bt, 50)                                   # the model's route at this size: no stored logits
+    streamed_top = bt.topk_idx.clone()
+    p.eval_kernels(bt, 50, stored=True)
+    assert torch.equal(bt.topk_idx, streamed_top)
     item_ids = torch.from_numpy(feed["item_list"].astype(np.int64)).cuda().view(-1)
     assert torch.equal(bt.ic[:, :128], p.tables["item"][item_ids])
     top = bt.topk_idx.long()
@@ -173,6 +207,8 @@ def test_c5_shape_fp32_50m_items_l200(hip_lib, tmp_path):
     # the highest table rows are reachable: the last row's score equals a direct dot product
     last = (bt.pred.double() @ p.tables["item"][-1].double())
     assert float((bt.logits[:, -1].double() - last).abs().max()) < 1e-4
+    bt._logits_store = None
+    assert p.logits_free32
     losses = [model.train(model.sess, records, 1e-3)[0] for _ in range(3)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
 
@@ -218,7 +254,10 @@ def test_c5_bf16_scoring_50m_items_l200(hip_lib, tmp_path):
     records = make_records(cat, B, L, seed=6)
     feed = emb.make_feed_dic_new(records)
     bt = p.load_feed(feed)
-    p.eval_kernels(bt, 50)
+    p.eval_kernels(bt, 50)                                   # slab-wise (no stored logits) at this size
+    streamed_top = bt.topk_idx.clone()
+    p.eval_kernels(bt, 50, stored=True)
+    assert torch.equal(bt.topk_idx, streamed_top)
     tgt = torch.from_numpy(feed["target_item_id"].astype(np.int64)).cuda()
     hist = torch.from_numpy(feed["item_list"].astype(np.int64)).cuda().view(-1)
     assert torch.equal(bt.ic[:, :128], p.item16[hist].float())       # history rows: the bf16 image, widened

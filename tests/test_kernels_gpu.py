@@ -903,3 +903,40 @@ def test_seq_chain_fwd_matches_the_three_products(ops, R, n_kv, n_x):
     # the relu mask the backward uses is exact where the pre-activation is not within rounding of zero
     clear = np.abs(z64) > 1e-4
     assert np.array_equal((zr.cpu().numpy() > 0)[clear], (z64 > 0)[clear])
+
+
+@pytest.mark.parametrize("rows,V,slab", [(5, 300000, 131072), (3, 65536 * 3, 65536), (2, 70000, 65536 * 2)])
+def test_topk_stream_equals_topk_on_the_stored_matrix(ops, rows, V, slab):
+    """mtam_topk_stream_slab / _finish (evaluation without stored logits, Model/base_model.py:194-202) against
+    mtam_topk on the whole matrix: identical lists, with equal values planted on both sides of slab and
+    segment boundaries (lower index first), a row whose best entries are all in the last partial segment, and
+    -inf / -0.0 entries."""
+    rng = np.random.default_rng(rows * 7 + V)
+    k = 50
+    x = rng.standard_normal((rows, V)).astype(np.float32)
+    seg = ops.TOPK_STREAM_SEG
+    # ties across a segment boundary and across a slab boundary, above everything else in the row
+    x[0, [min(i, V - 1) for i in (seg - 1, seg, seg + 1, slab - 1, slab, 5)]] = 9.0
+    x[1 % rows, V - 30:] = 7.0                         # the best 30 tie in the last (partial) segment
+    x[1 % rows, :40] = 7.0                             # ... with 40 more at the very start: lower indices win
+    x[rows - 1, 100:200] = -np.inf
+    x[rows - 1, 300] = -0.0
+    x[rows - 1, 301] = 0.0
+    full = dev(x)
+    want = torch.zeros((rows, k), dtype=torch.int32, device="cuda")
+    want_v = torch.zeros((rows, k), device="cuda")
+    ops.topk(full, V, rows, V, k, want, want_v)
+    ws = torch.full(((ops.topk_stream_workspace_bytes(rows, V, k) + 3) // 4,), float("nan"), device="cuda")
+    scratch = torch.empty((rows, slab), device="cuda")
+    for col0 in range(0, V, slab):
+        width = min(slab, V - col0)
+        scratch[:, :width] = full[:, col0:col0 + width]
+        ops.topk_stream_slab(scratch, slab, rows, col0, width, V, k, ws)
+    got = torch.zeros((rows, k), dtype=torch.int32, device="cuda")
+    got_v = torch.zeros((rows, k), device="cuda")
+    ops.topk_stream_finish(ws, rows, V, k, got, got_v)
+    assert torch.equal(got, want) and torch.equal(got_v, want_v)
+    ref = np.argsort(-x.astype(np.float64), axis=1, kind="stable")[:, :k]
+    assert np.array_equal(got.cpu().numpy(), ref)
+    with pytest.raises(RuntimeError):                  # a slab must start on a segment boundary
+        ops.topk_stream_slab(scratch, slab, rows, 1000, 10, V, k, ws)
