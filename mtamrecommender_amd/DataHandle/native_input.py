@@ -197,11 +197,14 @@ class NativeDataInput(object):
 
     _streams = 0
 
-    def __init__(self, recordset, batch_size, packer, index=None, prefetch=True, consumer=None):
+    def __init__(self, recordset, batch_size, packer, index=None, prefetch=True, consumer=None, shard=None):
         """``consumer``: name of this batch stream's arena pool inside the packer.  Default: a pool of its
         own per iterator; a trainer that builds one iterator per epoch passes a fixed name ("train", "eval")
         so that the pinned arenas are allocated once."""
         self.rs, self.batch_size, self.packer = recordset, int(batch_size), packer
+        # shard = (rank, world): data parallel -- this iterator packs only its rank's contiguous slice of every
+        # global batch (data_parallel.shard); ``batch.global_size`` is the size of the whole batch
+        self.shard = shard
         if consumer is None:
             NativeDataInput._streams += 1
             consumer = "stream%d" % NativeDataInput._streams
@@ -215,15 +218,26 @@ class NativeDataInput(object):
         self._pending = None
         # Pinned arenas are allocated HERE, on the caller's thread: the worker thread must not make HIP
         # calls (hipHostMalloc while the main thread captures a hipGraph invalidates the capture).
-        for size in {min(self.batch_size, n), n % self.batch_size}:
+        sizes = {min(self.batch_size, n), n % self.batch_size}
+        if shard is not None:
+            rank, world = shard
+            sizes = {(g * (rank + 1)) // world - (g * rank) // world for g in sizes}
+        for size in sizes:
             if size > 0:
                 packer._layout(size, self.consumer)
 
     def __iter__(self):
         return self
 
-    def _slice(self, i):
+    def _global_slice(self, i):
         return self.index[i * self.batch_size:min((i + 1) * self.batch_size, len(self.index))]
+
+    def _slice(self, i):
+        g = self._global_slice(i)
+        if self.shard is None:
+            return g
+        rank, world = self.shard
+        return g[(len(g) * rank) // world:(len(g) * (rank + 1)) // world]
 
     def _start(self, i):
         box = {}
@@ -251,6 +265,7 @@ class NativeDataInput(object):
             if "error" in box:
                 raise box["error"]
             batch = box["batch"]
+        batch.global_size = len(self._global_slice(self.i))
         self.i += 1
         return self.i, batch
 

@@ -79,6 +79,12 @@ class base_model(object):
         self.use_graph = os.environ.get("MTAM_HIP_GRAPH", "1") != "0"
         self._dp_mode = os.environ.get("MTAM_DP_GRAPH")       # None: decided at the first data-parallel step
         self._graphs = {}
+        # async_loss: train() hands back the loss of the PREVIOUS step (its own on the first call) instead of
+        # blocking on this step's -- the reference's sess.run blocks (:159-164), and with a blocking read-back the
+        # host cannot prepare batch t + 1 while the device runs step t.  Off by default (drop-in semantics);
+        # Train_main_process, which only averages and logs the losses, turns it on.  last_loss() drains.
+        self.async_loss = False
+        self._loss_ring, self._loss_slot, self._steps_issued = None, 0, 0
 
     # ------------------------------------------------------------ life cycle
     def init_variables(self, sess, path, var_list=None):
@@ -198,12 +204,13 @@ class base_model(object):
         if not self.use_graph:
             fn(bt)
             return
-        key = (kind, bt.B)
+        # the global batch (data parallel: 1 / gb is a kernel argument) is part of what a captured step bakes in
+        key = (kind, bt.B, getattr(self.path, "global_batch", None))
         g = self._graphs.get(key)
         if g is None:
-            if self._graphs.get((kind, bt.B, "warm")) is None:
+            if self._graphs.get(key + ("warm",)) is None:
                 fn(bt)                                   # first call: plain launches (also warms caches)
-                self._graphs[(kind, bt.B, "warm")] = True
+                self._graphs[key + ("warm",)] = True
                 return
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -227,6 +234,12 @@ class base_model(object):
         the fused form has only been run with a one-rank group (this build's GPU box has one GPU), and a
         collective that misbehaves inside a replayed graph cannot be recovered from -- ``fused`` otherwise."""
         p = self.path
+        if getattr(p, "sharded", None) is not None:
+            # large catalogs: forward + backward as one graph, then the row-sharded exchange and update eagerly
+            # (a handful of launches between collectives; the step is milliseconds long at these sizes)
+            self._run("train_fb", bt, p.forward_backward_kernels)
+            p.sharded.exchange_and_apply(bt)
+            return
         if p.allreduce_fn is None:
             self._run("train", bt, p.train_kernels)
             return
@@ -239,7 +252,7 @@ class base_model(object):
             except Exception as e:                       # capture of the collective not supported here
                 self.logger.info("fused data-parallel graph unavailable (%s): using split graphs" % (e,))
                 self._dp_mode = "split"
-                self._graphs.pop(("train_dp", bt.B), None)
+                self._graphs.pop(("train_dp", bt.B, getattr(p, "global_batch", None)), None)
                 torch.cuda.synchronize()
         self._run("train_fb", bt, p.forward_backward_kernels)
         p.allreduce_fn(p, bt)
@@ -265,10 +278,37 @@ class base_model(object):
         """One optimizer step on one batch -> (loss, summary) (reference :150-167)."""
         bt, _ = self._load(batch_data, learning_rate)
         self.step_train(bt)
-        loss = bt.loss.cpu().numpy()
+        if self.async_loss:
+            loss = self._loss_one_step_late(bt)
+        else:
+            loss = bt.loss.cpu().numpy()
         summary = {"normalized Training Loss": float(loss[0]), "l2_norm": float(loss[1]),
                    "Training Loss": float(loss[2]), "Learning_rate": float(learning_rate)}
         return float(loss[0]), summary
+
+    def _loss_one_step_late(self, bt):
+        """Queue a device -> pinned-host copy of this step's loss behind the step and return the previous step's
+        (two pinned slots, one event each): the host never waits for the step it has just launched."""
+        if self._loss_ring is None:
+            self._loss_ring = [(torch.zeros(3).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+        cur = self._loss_slot
+        host, ev = self._loss_ring[cur]
+        host.copy_(bt.loss, non_blocking=True)
+        ev.record()
+        first = self._steps_issued == 0
+        self._steps_issued += 1
+        self._loss_slot = 1 - cur
+        host, ev = self._loss_ring[cur if first else 1 - cur]
+        ev.synchronize()
+        return host.numpy().copy()
+
+    def last_loss(self):
+        """The loss of the most recent step (waits for it)."""
+        if self._loss_ring is None or self._steps_issued == 0:
+            return None
+        host, ev = self._loss_ring[1 - self._loss_slot]
+        ev.synchronize()
+        return float(host[0])
 
     def metrics_topK(self, sess, batch_data, global_step, topk):
         """hr/ndcg @ 1, 5, 10, 30, 50 over the full catalog (reference :188-213;

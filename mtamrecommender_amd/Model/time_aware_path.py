@@ -75,7 +75,13 @@ class _Batch(object):
         # step needs one host->device (or device->device) copy and can be replayed from a hipGraph.
         self.offsets, o = arena_layout(B, L)
         self.arena = torch.zeros(o, dtype=torch.int32, device=dev)
-        self.host_arena = torch.zeros(o, dtype=torch.int32).pin_memory()
+        # two pinned host copies used in turn, each guarded by an event recorded behind its host -> device copy:
+        # with an asynchronous loss read-back the host fills batch t + 1 while the copy of batch t may still be
+        # in flight
+        self._host_ring = [torch.zeros(o, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self._host_events = [None, None]
+        self._host_slot = 0
+        self.host_arena = self._host_ring[0]
         self.feed = {name: self._view(self.arena, name) for name in self.offsets}
         self.host = {name: self._view(self.host_arena, name) for name in self.offsets}
         # forward activations
@@ -151,6 +157,22 @@ class _Batch(object):
     def logits(self):
         return self.logits_store[:, :self._path_V]
 
+    def next_host_arena(self):
+        """Switch to the other pinned arena (waiting, if need be, for the copy that last read it)."""
+        self._host_slot = 1 - self._host_slot
+        ev = self._host_events[self._host_slot]
+        if ev is not None:
+            ev.synchronize()
+        self.host_arena = self._host_ring[self._host_slot]
+        self.host = {name: self._view(self.host_arena, name) for name in self.offsets}
+
+    def upload(self):
+        """host arena -> device arena (asynchronous; the event guards the host buffer's next use)."""
+        self.arena.copy_(self.host_arena, non_blocking=True)
+        if self._host_events[self._host_slot] is None:
+            self._host_events[self._host_slot] = torch.cuda.Event()
+        self._host_events[self._host_slot].record()
+
     def _view(self, arena, name):
         o, n, shape, dt = self.offsets[name]
         v = arena[o:o + n]
@@ -198,8 +220,14 @@ class TimeAwarePath(object):
             o += int(tables[k].size)
         self.n_total = o
         self.item_rows = tables["item"].shape[0]
+        # the item region is allocated with its row count rounded up to a multiple of 8, so that the
+        # data-parallel exchange can cut it into 1, 2, 4 or 8 equal row ranges (data_parallel.ShardedItemExchange);
+        # the pad rows are zero, never looked up, scored or updated (every kernel gets the true counts)
+        self.item_rows_pad = (self.item_rows + 7) // 8 * 8
+        self.n_alloc = o + (self.item_rows_pad - self.item_rows) * D
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_p, self.flat_g, self.flat_m, self.flat_v = z(o), z(o), z(o), z(o)
+        self.flat_p, self.flat_g, self.flat_m, self.flat_v = (z(self.n_alloc), z(self.n_alloc), z(self.n_alloc),
+                                                              z(self.n_alloc))
         self.params = self.flat_p[:P]
         self.grads = self.flat_g[:P]
         self.m, self.v = self.flat_m[:P], self.flat_v[:P]
@@ -224,12 +252,13 @@ class TimeAwarePath(object):
         # B=128: 3,709 rows 0.3012 vs 0.3049 ms, 8,003 rows 0.3128 vs 0.3095, 30,003 rows 0.379 vs 0.352 --
         # every 32-row slab flushes a [128, 128] share of d_pred by atomics, which stops paying beyond a few
         # thousand rows.  MTAM_FUSED_SCORE_MAX_ROWS overrides the limit (0 = never)
-        # Large catalogs (>= MTAM_FUSED_SCORE_MIN_LARGE_ROWS, default 262,144) never materialise [B, V] either
-        # (SURVEY.md K9): the same two kernels, each workgroup owning a contiguous range of slabs with its
-        # share of d_pred in accumulator registers for the whole range (one flush of <= 512 x 64 KB)
+        # Large catalogs (>= MTAM_FUSED_SCORE_MIN_LARGE_ROWS, default 65,536) never materialise [B, V] either
+        # (SURVEY.md K9): the same two entry points, each workgroup owning a contiguous range of slabs with its
+        # share of d_pred in accumulator registers for the whole range (one flush of <= 512 x 64 KB); from
+        # 65,536 rows on they run the fp32 products as six bf16 MFMA terms per product (csrc/score32.hip, x3)
         self.logits_free32 = score_dtype == "f32" and \
             (self.item_rows <= int(os.environ.get("MTAM_FUSED_SCORE_MAX_ROWS", "4096")) or
-             self.item_rows >= int(os.environ.get("MTAM_FUSED_SCORE_MIN_LARGE_ROWS", "262144")))
+             self.item_rows >= int(os.environ.get("MTAM_FUSED_SCORE_MIN_LARGE_ROWS", "65536")))
         if self.logits_free32:
             self.nb_item = ops.score32_sq_partials(self.item_rows)
         self.item16 = None
@@ -248,9 +277,16 @@ class TimeAwarePath(object):
         # weight-gradient GEMMs next to the serial chain: 388 us/step vs 366 us in one stream at B=128; the
         # cross-queue graph edges cost more than the overlap won, so the step is single-stream.)
         self.allreduce_fn = None        # set by data_parallel.attach()
-        self.world_size = 1             # the loss is a mean over world_size * B samples
+        self.sharded = None             # data_parallel.ShardedItemExchange: replaces allreduce_fn + clip_and_apply
+        self.world_size = 1             # the loss is a mean over world_size * B samples ...
+        self.global_batch = None        # ... or over exactly this many when the ranks' batches differ in size
 
     # ----------------------------------------------------------------- helpers
+    def gb(self, bt):
+        """The number of samples the cross-entropy is a mean over: the GLOBAL batch (Model/base_model.py:322 is a
+        reduce_mean over the batch; data-parallel ranks hold slices of it)."""
+        return int(self.global_batch) if self.global_batch else bt.B * self.world_size
+
     def seg(self, name, flat=None):
         return self.layout.view(self.params if flat is None else flat, name)
 
@@ -269,8 +305,9 @@ class TimeAwarePath(object):
         """Host feed arrays (Embedding.make_feed_dic_new) [+ learning rate] -> the fixed
         device arena, one pinned host->device copy."""
         bt = self.batch(len(feed["user_id"]))
+        bt.next_host_arena()
         self.fill_host(bt, feed, lr)
-        bt.arena.copy_(bt.host_arena, non_blocking=True)
+        bt.upload()
         return bt
 
     def stage(self, feed, lr):
@@ -308,10 +345,10 @@ class TimeAwarePath(object):
         sq = part[self.nb_dense:] if self.tf_compat else None
         if self.logits_free32:
             ops.score32_bwd(self.tables["item"], bt.pred, bt.lse, bt.feed["target_item_id"], bt.B, V,
-                            1.0 / (bt.B * self.world_size), bt.d_pred, self.g_tab["item"], sq)
+                            1.0 / self.gb(bt), bt.d_pred, self.g_tab["item"], sq)
             return
         if self.score_dtype == "bf16":
-            gb = bt.B * self.world_size
+            gb = self.gb(bt)
             ops.score16_bwd(self.item16, bt.pred16, bt.lse, bt.feed["target_item_id"], bt.B, V, 1.0 / gb,
                             bt.d_pred, self.g_tab["item"], sq)
             return
@@ -401,7 +438,7 @@ class TimeAwarePath(object):
         if self.score_dtype == "bf16" or self.logits_free32:
             return              # lse and cross entropy came out of score_forward; G is formed inside score_backward
         B, V = bt.B, self.item_rows
-        gb = B * self.world_size
+        gb = self.gb(bt)
         # logits -> lse, ce; then d_logits in place
         # the loss scalar itself is reduced in the step epilogue (clip_and_apply), off the chain
         ops.softmax_ce_loss(bt.logits_store, bt.ld_logits, bt.feed["target_item_id"], B, V, 1.0 / gb, bt.lse, bt.ce,
@@ -522,7 +559,7 @@ class TimeAwarePath(object):
         else:
             n_g = self.n_total
             n = ops.sqnorm_blocks(self.n_total)
-        gb = bt.B * self.world_size
+        gb = self.gb(bt)
         ops.sqnorm_clip_scale(self.flat_g, n_g, part, 0, n, self.clip, self.scale, bt.feed["lr"],
                               self.adam_state, self.ticket, bt.l2_partial, bt.l2_partial.numel(), bt.ce, bt.B,
                               self.reg, 1.0 / gb, bt.loss)
@@ -548,6 +585,9 @@ class TimeAwarePath(object):
     def train_kernels(self, bt):
         """Everything between feed upload and loss read-back; capturable."""
         self.forward_backward_kernels(bt)
+        if self.sharded is not None:
+            self.sharded.exchange_and_apply(bt)
+            return
         if self.allreduce_fn is not None:
             self.allreduce_fn(self, bt)
         self.clip_and_apply(bt)

@@ -142,6 +142,9 @@ class model_parameter(object):
                          'make_feed_dic_new per step')
         f.DEFINE_boolean('swallow_step_errors', False,
                          'log-and-continue on a failed step like train_process.py:369-371')
+        f.DEFINE_boolean('async_loss', True,
+                         'Train_main_process: model.train() returns the loss one step late instead of waiting for the '
+                         'step it has just launched (the logged averages cover the same steps, shifted by one)')
         f.DEFINE_boolean('allow_pickle_parameters', False,
                          'load a parameters.pkl written by the reference (Prepare/prepare_data_base.py:99-101) when no '
                          'parameters.json sits next to it; unpickling executes what the file says, so opt in only for '

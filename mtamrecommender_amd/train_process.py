@@ -21,6 +21,7 @@ data adapters are missing from its tree, so records come from the
 synthetic generator unless ``train_set`` / ``test_set`` are handed in.
 """
 import math
+import os
 import random
 import time
 
@@ -57,6 +58,14 @@ def average_metrics(per_batch):
     return tuple(float(np.mean([m[i] for m in per_batch])) for i in range(10))
 
 
+class _GlobalBatch(list):
+    """A rank's slice of a global batch (a list of records) that remembers the size of the whole batch."""
+
+    def __init__(self, records, global_size):
+        super(_GlobalBatch, self).__init__(records)
+        self.global_size = global_size
+
+
 class Train_main_process(object):
 
     def __init__(self, experiment_name="MTAMb1_movielen", argv=None, train_set=None, test_set=None,
@@ -87,6 +96,18 @@ class Train_main_process(object):
         self.emb = Behavior_embedding_time_aware_attention(
             is_training=self.FLAGS.is_training, user_count=self.user_count, item_count=self.item_count,
             category_count=self.category_count, max_length_seq=L)
+        # Data parallel (one process per GPU, torch.distributed.run sets WORLD_SIZE / RANK / LOCAL_RANK): every rank
+        # walks the same global batches (same shuffle seed) and trains on its slice; see data_parallel.py
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(device)
+            if not dist.is_initialized():
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                dist.init_process_group(backend="nccl", device_id=torch.device(device))
         self.device = device
         self.global_step = 0
         self.one_epoch_step = 0
@@ -119,6 +140,12 @@ class Train_main_process(object):
         else:
             raise NotImplementedError("experiment_type %r has no HIP path (MTAM and the time-aware "
                                       "self-attention model only)" % self.FLAGS.experiment_type)
+        # the trainer only averages and logs losses: let train() return them one step late instead of blocking
+        self.model.async_loss = bool(getattr(self.FLAGS, "async_loss", True))
+        if self.world > 1:
+            from . import data_parallel
+            data_parallel.attach(self.model.path, self.world)
+            data_parallel.broadcast_parameters(self.model.path)
         return self.model
 
     # ------------------------------------------------------------------- feeds
@@ -135,13 +162,20 @@ class Train_main_process(object):
             self._order = list(range(len(self.train_set)))
 
     def _train_batches(self):
+        """(step, batch) over the epoch; data parallel: ``train_batch_size`` is the GLOBAL batch and every rank gets
+        its contiguous slice of each (sizes differ by at most one; the loss stays the mean over the global batch)."""
+        shard = (self.rank, self.world) if self.world > 1 else None
         if not self._native:
             random.shuffle(self.train_set)
-            return DataInput(self.train_set, self.FLAGS.train_batch_size)
+            batches = DataInput(self.train_set, self.FLAGS.train_batch_size)
+            if shard is None:
+                return batches
+            from .data_parallel import shard as cut
+            return ((i, _GlobalBatch(cut(b, self.rank, self.world), len(b))) for i, b in batches)
         from .DataHandle.native_input import NativeDataInput
         random.shuffle(self._order)          # the same permutation random.shuffle(train_set) would apply
         return NativeDataInput(self._train_rs, self.FLAGS.train_batch_size, self._packer, index=self._order,
-                               consumer="train")
+                               consumer="train", shard=shard)
 
     def _test_batches(self):
         if not self._native:
@@ -165,7 +199,8 @@ class Train_main_process(object):
         return avg
 
     def save_model(self):
-        self.model.save(self.sess, self.global_step)
+        if self.rank == 0:
+            self.model.save(self.sess, self.global_step)
 
     # -------------------------------------------------------------------- loop
     def train(self, max_steps=None):
@@ -189,6 +224,8 @@ class Train_main_process(object):
                     learning_rate = next_learning_rate(learning_rate, self.FLAGS.learning_rate,
                                                        self.FLAGS.decay_rate, self.global_step)
                     add_summary = bool(self.global_step % self.FLAGS.display_freq == 0)
+                    if self.world > 1:      # the loss is a mean over the whole batch, not over this rank's slice
+                        self.model.path.global_batch = train_batch_data.global_size
                     step_loss, merge = self.model.train(self.sess, train_batch_data, learning_rate,
                                                         add_summary, self.global_step, epoch)
                     self.model.train_writer.add_summary(merge, self.global_step)
@@ -220,7 +257,7 @@ class Train_main_process(object):
             self.now_epoch = self.now_epoch + 1
             if max_steps is not None and self.global_step >= max_steps:
                 break
-        self.model.save(self.sess, self.global_step)
+        self.save_model()
         self.logger.info('Finished')
 
 

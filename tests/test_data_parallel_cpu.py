@@ -52,3 +52,138 @@ def test_two_rank_gradient_exchange_matches_full_batch(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     worst = float(np.load(os.path.join(str(tmp_path), "worst.npy"))[0])
     assert worst < 1e-12
+
+
+# ------------------------------------------------------------------ row-sharded item-table exchange
+class _TorchStepKernels(object):
+    """CPU twin of data_parallel.HipStepKernels: the same five operations with torch ops (Adam as csrc/optim.hip
+    writes it: dense form m += (g - m)(1 - b1) before `sparse_begin`, IndexedSlices form m = m b1 + g (1 - b1) after)."""
+
+    def sq_sum(self, g, weight, out, accumulate):
+        t = weight * float((g.double() ** 2).sum())
+        out[0] = out[0] + t if accumulate else t
+
+    def clip_scale(self, sq_total, clip, scale, lr, adam_state):
+        norm = np.float32(np.sqrt(np.float32(sq_total[0].item())))
+        scale[0] = float(np.float32(clip) * min(np.float32(1.0) / norm, np.float32(1.0) / np.float32(clip)))
+        scale[1] = float(norm)
+        b1p, b2p = np.float32(adam_state[4].item()), np.float32(adam_state[5].item())
+        adam_state[0] = float(np.float32(lr[0].item()) * np.sqrt(np.float32(1.0) - b2p) / (np.float32(1.0) - b1p))
+        adam_state[4] = float(b1p * np.float32(adam_state[1].item()))
+        adam_state[5] = float(b2p * np.float32(adam_state[2].item()))
+
+    def loss(self, bt, reg, ce_scale):
+        bt.loss[0] = reg * bt.l2 + bt.ce.sum() * ce_scale
+        bt.loss[1] = bt.l2
+        bt.loss[2] = bt.ce.sum() * ce_scale
+
+    def adam(self, p, m, v, g, scale, hyper, sparse_begin):
+        lr_t, b1, b2, eps = (hyper[i].clone() for i in range(4))
+        gs = g * scale[0]
+        n = p.numel()
+        sb = min(int(sparse_begin), n)
+        m[:sb] += (gs[:sb] - m[:sb]) * (1.0 - b1)
+        m[sb:] = m[sb:] * b1 + gs[sb:] * (1.0 - b1)
+        v[:sb] += (gs[:sb] * gs[:sb] - v[:sb]) * (1.0 - b2)
+        v[sb:] = v[sb:] * b2 + gs[sb:] * gs[sb:] * (1.0 - b2)
+        p -= lr_t * m / (torch.sqrt(v) + eps)
+
+
+class _FakeBatch(object):
+    def __init__(self, B, lr):
+        self.B = B
+        self.feed = {"lr": torch.tensor([lr], dtype=torch.float32)}
+        self.loss = torch.zeros(3)
+        self.l2, self.ce = 0.0, torch.zeros(B)
+
+
+class _FakePath(object):
+    """The attributes of TimeAwarePath the exchange touches, on CPU tensors."""
+    optimizer = "adam"
+
+    def __init__(self, n_dense, small_rows, item_rows, seed):
+        D = 128
+        g = torch.Generator().manual_seed(seed)
+        self.n_dense = n_dense
+        self.tab_off = {"item": n_dense + small_rows * D}
+        self.item_rows, self.item_rows_pad = item_rows, (item_rows + 7) // 8 * 8
+        self.n_total = self.tab_off["item"] + item_rows * D
+        self.n_alloc = self.tab_off["item"] + self.item_rows_pad * D
+        z = lambda: torch.zeros(self.n_alloc)
+        self.flat_p, self.flat_g, self.flat_m, self.flat_v = z(), z(), z(), z()
+        self.flat_p[:self.n_total] = torch.randn(self.n_total, generator=g) * 0.1
+        self.flat_m[:self.n_total] = torch.randn(self.n_total, generator=g) * 0.01
+        self.flat_v[:self.n_total] = torch.rand(self.n_total, generator=g) * 1e-3
+        self.clip, self.reg = 1.0, 5e-5
+        self.scale = torch.zeros(2)
+        self.adam_state = torch.tensor([0.0, 0.9, 0.999, 1e-8, 0.9 ** 3, 0.999 ** 3, 0.0, 0.0])
+        self.global_batch, self.world_size, self.device = None, 1, "cpu"
+        self.refreshed = 0
+
+    def gb(self, bt):
+        return bt.B * self.world_size
+
+    def refresh_item16(self):
+        self.refreshed += 1
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from mtamrecommender_amd import data_parallel
+    D = 128
+    # the same replica on every rank; every rank's OWN gradient (seeded by rank); item rows not a multiple of 8
+    path = _FakePath(n_dense=4096, small_rows=37, item_rows=1003, seed=1)
+    path.world_size = world
+    gen = torch.Generator().manual_seed(100 + rank)
+    # multiples of 2^-12: sums over ranks are exact in fp32, so the comparison does not depend on the order in
+    # which a collective happens to add its operands (gloo's ring cuts buffers of different sizes differently)
+    path.flat_g[:path.n_total] = torch.round(torch.randn(path.n_total, generator=gen) * 0.02 * 4096) / 4096
+    bt = _FakeBatch(B=6, lr=1e-3)
+    bt.l2, bt.ce = 3.0 + rank, torch.full((6,), 2.0 + rank)
+    # ---- the replicated update on the all-reduced gradient (what the flat exchange computes), kept aside
+    ref = _FakePath(n_dense=4096, small_rows=37, item_rows=1003, seed=1)
+    ref.world_size = world
+    g_all = path.flat_g.clone()
+    dist.all_reduce(g_all)
+    k = _TorchStepKernels()
+    sq = torch.zeros(1, dtype=torch.float64)
+    k.sq_sum(g_all[:ref.n_total], 1.0, sq, False)
+    k.clip_scale(sq, ref.clip, ref.scale, bt.feed["lr"], ref.adam_state)
+    k.adam(ref.flat_p[:ref.n_total], ref.flat_m[:ref.n_total], ref.flat_v[:ref.n_total], g_all[:ref.n_total], ref.scale,
+           ref.adam_state, ref.n_dense)
+    # ---- the row-sharded exchange
+    ex = data_parallel.ShardedItemExchange(path, world, rank, kernels=k)
+    assert ex.shard_elems * world == path.item_rows_pad * D and ex.lo == path.tab_off["item"] + rank * ex.shard_elems
+    ex.exchange_and_apply(bt)
+    rel = abs(float(path.scale[1]) - float(ref.scale[1])) / float(ref.scale[1])
+    same = (torch.equal(path.flat_p, ref.flat_p) and torch.equal(path.adam_state, ref.adam_state))
+    own = slice(ex.lo, ex.hi_true)
+    same_slots = (torch.equal(path.flat_m[own], ref.flat_m[own]) and torch.equal(path.flat_v[own], ref.flat_v[own]) and
+                  torch.equal(path.flat_m[:ex.off_item], ref.flat_m[:ex.off_item]))
+    pad_zero = not bool(path.flat_p[path.n_total:].any()) and not bool(path.flat_g[path.n_total:].any())
+    # loss = reg * (l2 summed over ranks) + (ce summed over ranks) / global batch
+    want_loss = path.reg * sum(3.0 + r for r in range(world)) + sum(6 * (2.0 + r) for r in range(world)) / (6 * world)
+    np.save(os.path.join(out_dir, "sharded_%d.npy" % rank),
+            np.array([rel, float(same), float(same_slots), float(pad_zero), float(bt.loss[0]) - want_loss,
+                      float(torch.equal(path.scale, ref.scale)), float(path.refreshed)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_item_exchange_equals_the_replicated_update(tmp_path, world):
+    """reduce-scatter by row range + shard-owned clip contribution and Adam + all-gather (gloo stand-ins for the
+    two collectives it lacks) against dense Adam on the all-reduced gradient: parameters, both slots and the Adam
+    state bit for bit on every rank, 1,003 item rows (pad rows untouched), loss summed over ranks."""
+    port = 29500 + (os.getpid() % 2000) + 7 * world
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        rel, same, same_slots, pad_zero, dloss, same_scale, refreshed = np.load(
+            os.path.join(str(tmp_path), "sharded_%d.npy" % rank))
+        assert rel < 1e-7 and same == 1.0 and same_slots == 1.0 and pad_zero == 1.0, (rank, rel, same, same_slots)
+        assert abs(dloss) < 1e-5 and refreshed == 1.0
+        assert same_scale == 1.0            # the clip scale itself came out bit-identical too

@@ -198,11 +198,49 @@ def test_data_parallel_code_path_single_rank(hip_lib, tmp_path, dp_mode):
             lb, _ = model_b.train(model_b.sess, records, 1e-3)
             assert abs(la - lb) <= 1e-6 * abs(la), step
         assert model_b._dp_mode == dp_mode                  # "fused" did not fall back
-        assert (("train_dp", 32) in model_b._graphs) == (dp_mode == "fused")
+        assert (("train_dp", 32, None) in model_b._graphs) == (dp_mode == "fused")
         va, vb = model_a.get_variables(), model_b.get_variables()
         for k in va:
             assert np.abs(va[k] - vb[k]).max() <= 2.1e-3 * 4, k
             assert (np.abs(va[k] - vb[k]) > 2e-5).mean() < 2e-3, k
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("score_dtype", ["f32", "bf16"])
+def test_sharded_item_exchange_single_rank(hip_lib, tmp_path, score_dtype):
+    """data_parallel.ShardedItemExchange (reduce-scatter by row range, shard-owned clip share and Adam, all-gather)
+    through the real kernels and a one-rank RCCL group: the same losses and parameters as the single-GPU step with
+    the true clip norm.  1,003 item rows: the padded tail of the flat buffers stays zero."""
+    import torch.distributed as dist
+    from mtamrecommender_amd import data_parallel
+    os_env = __import__("os").environ
+    os_env.setdefault("MASTER_ADDR", "127.0.0.1")
+    os_env["MASTER_PORT"] = "29619" if score_dtype == "f32" else "29620"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        kw = dict(items=1000, score_dtype=score_dtype)
+        model_a, FLAGS, records = build(tmp_path, 32, 50, 1, 1, **kw)
+        model_b, _, _ = build(tmp_path, 32, 50, 1, 1, **kw)
+        model_a.path.tf_compat = False
+        data_parallel.attach(model_b.path, 1, force=True, shard_items=True)
+        assert model_b.path.sharded is not None and model_b.path.item_rows_pad == 1008
+        data_parallel.broadcast_parameters(model_b.path)
+        for step in range(4):
+            la, _ = model_a.train(model_a.sess, records, 1e-3)
+            lb, _ = model_b.train(model_b.sess, records, 1e-3)
+            # (bf16: an update that differs in the last fp32 bit can flip the rounding of a scoring-copy entry)
+            assert abs(la - lb) <= (2e-6 if score_dtype == "f32" else 3e-5) * abs(la), step
+        pa, pb = model_a.path, model_b.path
+        assert abs(float(pa.scale[1]) - float(pb.scale[1])) <= 1e-5 * float(pa.scale[1])
+        va, vb = model_a.get_variables(), model_b.get_variables()
+        for k in va:
+            assert np.abs(va[k] - vb[k]).max() <= 2.1e-3 * 4, k
+            assert (np.abs(va[k] - vb[k]) > 2e-5).mean() < 2e-3, k
+        for flat in (pb.flat_p, pb.flat_g, pb.flat_m, pb.flat_v):
+            assert not bool(flat[pb.n_total:].any())
+        if score_dtype == "bf16":
+            assert torch.equal(pb.item16.view(torch.int16), pb.tables["item"].bfloat16().view(torch.int16))
     finally:
         dist.destroy_process_group()
 

@@ -162,3 +162,27 @@ def test_eval_between_two_train_batches_leaves_the_prefetched_train_batch_alone(
 def torch_equal(x, y):
     import torch
     return torch.equal(x, y)
+
+
+def test_sharded_iterators_partition_every_global_batch(host):
+    """Data parallel: rank r's iterator packs its contiguous slice of each global batch (data_parallel.shard) and
+    reports the global size; the slices of all ranks are a partition, in order."""
+    from mtamrecommender_amd import data_parallel
+    from mtamrecommender_amd.DataHandle.native_input import BatchPacker, NativeDataInput, RecordSet, shuffled_index
+    from mtamrecommender_amd.Embedding.Behavior_embedding_time_aware_attention import \
+        Behavior_embedding_time_aware_attention
+    cat, records = _records(n=37, L=12)
+    emb = Behavior_embedding_time_aware_attention(True, cat.user_count, cat.item_count, cat.category_count, 12)
+    emb.init_placeholders()
+    rs = RecordSet.from_records(records)
+    packer = BatchPacker(12, emb)
+    order = shuffled_index(len(rs), 5)
+    world = 3
+    its = [NativeDataInput(rs, 10, packer, index=order, shard=(r, world)) for r in range(world)]
+    whole = NativeDataInput(rs, 10, packer, index=order)
+    for (step, g), *parts in zip(whole, *its):
+        assert all(s == step for s, _ in parts)
+        assert all(b.global_size == len(g) for _, b in parts)
+        assert np.array_equal(np.concatenate([b.index for _, b in parts]), g.index)
+        want = [data_parallel.shard(list(g.index), r, world) for r in range(world)]
+        assert [list(b.index) for _, b in parts] == want

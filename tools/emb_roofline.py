@@ -21,7 +21,7 @@ from mtamrecommender_amd import hip_ops as ops  # noqa: E402
 L, D = 50, 128
 
 
-def make_case(B, V, dist="zipf", seed=1234, n_cat=304, n_user=4835):
+def make_case(B, V, dist="zipf", seed=1234, n_cat=304, n_user=4835, tables=None):
     rng = np.random.Generator(np.random.PCG64(seed))
     sl = rng.integers(2, L + 1, size=B)
     live = np.arange(L)[None, :] < sl[:, None]
@@ -38,13 +38,16 @@ def make_case(B, V, dist="zipf", seed=1234, n_cat=304, n_user=4835):
     case = dict(B=B, V=V, item_ids=t(items), cat_ids=t(cats), pos_ids=t(pos),
                 user_ids=t(rng.integers(0, n_user, size=B)), seq_len=t(sl))
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev).uniform_(-0.2, 0.2)
-    case.update(item=f(V, D), cat=f(n_cat, D), pos=f(L + 3, D), user=f(n_user, D))
     R = B * L
+    if tables is None:
+        case.update(item=f(V, D), cat=f(n_cat, D), pos=f(L + 3, D), user=f(n_user, D),
+                    g_item=torch.zeros(V, D, device=dev), g_cat=torch.zeros(n_cat, D, device=dev),
+                    g_pos=torch.zeros(L + 3, D, device=dev), g_user=torch.zeros(n_user, D, device=dev))
+    else:       # another id / activation set over the same tables
+        case.update({k: tables[k] for k in ("item", "cat", "pos", "user", "g_item", "g_cat", "g_pos", "g_user")})
     case.update(ic=f(R, 2 * D), pos_out=f(R, D), user_out=f(B, D), d_ic=f(R, 2 * D), d_pos=f(R, D),
                 l2=torch.zeros(ops.emb_gather_partials(B, L), device=dev),
-                sq=torch.zeros(ops.emb_scatter_partials(B, L), device=dev),
-                g_item=torch.zeros(V, D, device=dev), g_cat=torch.zeros(n_cat, D, device=dev),
-                g_pos=torch.zeros(L + 3, D, device=dev), g_user=torch.zeros(n_user, D, device=dev))
+                sq=torch.zeros(ops.emb_scatter_partials(B, L), device=dev))
     case["live_rows"] = int(live.sum()) * 3 + B
     return case
 
@@ -60,14 +63,18 @@ def scatter(c):
                             c["g_item"], c["g_cat"], c["g_pos"], c["g_user"], c["sq"])
 
 
-def graph_time(fn, reps, replays=10):
-    for _ in range(3):
-        fn()
+def graph_time(fns, reps, replays=10):
+    """fns: callables doing the same work on different buffer sets; the graph walks them in turn."""
+    if callable(fns):
+        fns = [fns]
+    reps = max(reps, len(fns)) // len(fns) * len(fns)
+    for f in fns[:3]:
+        f()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for _ in range(reps):
-            fn()
+        for i in range(reps):
+            fns[i % len(fns)]()
     g.replay()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -84,20 +91,26 @@ def sweep():
     for V in (3709, 1000003, 10000003):
         for B in (128, 512, 2048, 8192):
             for dist in ("zipf", "uniform"):
+                # enough distinct (ids, activation buffers) sets that a launch never finds its rows in the
+                # 256 MiB Infinity Cache: >= 320 MB of activations in rotation (tables shared)
+                per_set = B * L * 3 * D * 4 * 2
+                nset = max(1, min(32, (320 << 20) // per_set + 1))
                 c = make_case(B, V, dist)
+                cases = [c] + [dict(c, **{k: v for k, v in make_case(B, V, dist, seed=1234 + i, tables=c).items()})
+                               for i in range(1, nset)]
                 reps = 50 if B <= 512 else 10
-                tg = graph_time(lambda: gather(c), reps)
-                ts = graph_time(lambda: scatter(c), reps)
+                tg = graph_time([(lambda cc: (lambda: gather(cc)))(cc) for cc in cases], reps)
+                ts = graph_time([(lambda cc: (lambda: scatter(cc)))(cc) for cc in cases], reps)
                 gb = (3 * L + 1) * (2 * D * 4 + 4) * B
                 sb = (3 * L + 1) * (3 * D * 4 + 4) * B
-                row = dict(V=V, B=B, dist=dist, gather_us=tg * 1e6, gather_GBs=gb / tg / 1e9,
+                row = dict(V=V, B=B, dist=dist, buffer_sets=nset, gather_us=tg * 1e6, gather_GBs=gb / tg / 1e9,
                            gather_frac_8TBs=gb / tg / 8e12, scatter_us=ts * 1e6, scatter_GBs_raw=sb / ts / 1e9,
                            scatter_frac_8TBs_raw=sb / ts / 8e12,
                            scatter_live_GBs=c["live_rows"] * (3 * D * 4 + 4) / ts / 1e9,
                            atomic_added_GBs=c["live_rows"] * D * 4 / ts / 1e9)
                 out.append(row)
                 print(json.dumps(row), flush=True)
-                del c
+                del c, cases
                 torch.cuda.empty_cache()
     return out
 

@@ -48,8 +48,29 @@ int main() {
     hipEventRecord(e0, 0);
     for (int i = 0; i < 50; ++i) mtam_tagru_bwd(ds, nullptr, x, tl, sl, wg, wc, tv, save, B, L, dxp, rh, dxt, dtv, nullptr);
     hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms_b, e0, e1);
-    printf("stamped build: fwd %.1f us, bwd %.1f us per launch (B=%d, L=%d)\n", ms_f * 20.f, ms_b * 20.f, B, L);
+    printf("fwd %.1f us, bwd %.1f us per launch (B=%d, L=%d)\n", ms_f * 20.f, ms_b * 20.f, B, L);
   }
+  {   // the launches' fixed part: the same kernels on sequences of length 1 (no recurrent step at all)
+    std::vector<int32_t> one(B, 1);
+    int32_t *sl1;
+    hipMalloc(&sl1, B * 4);
+    hipMemcpy(sl1, one.data(), B * 4, hipMemcpyHostToDevice);
+    for (int len : {1, 13, 26}) {
+      std::vector<int32_t> v(B, len);
+      hipMemcpy(sl1, v.data(), B * 4, hipMemcpyHostToDevice);
+      for (int i = 0; i < 5; ++i) mtam_tagru_fwd(xp, x, tl, sl1, wg, wc, tv, B, L, hs, sh, save, nullptr);
+      hipDeviceSynchronize();
+      float ms_f, ms_b;
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 50; ++i) mtam_tagru_fwd(xp, x, tl, sl1, wg, wc, tv, B, L, hs, sh, save, nullptr);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms_f, e0, e1);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 50; ++i) mtam_tagru_bwd(ds, nullptr, x, tl, sl1, wg, wc, tv, save, B, L, dxp, rh, dxt, dtv, nullptr);
+      hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms_b, e0, e1);
+      printf("seq_len %2d (%2d steps): fwd %.1f us, bwd %.1f us per launch\n", len, len - 1, ms_f * 20.f, ms_b * 20.f);
+    }
+  }
+#ifdef MTAM_GRU_STAMPS
   unsigned long long st[2][8][8];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_gru_stamps), sizeof(st));
   const char *fn[8] = {"reads+T+gate FMAs", "reduce+sigmoid+LDS write", "barrier 1", "rh reads+cand FMAs+reduce",
@@ -64,5 +85,6 @@ int main() {
     for (int i = 0; i < 8; ++i) tot += st[k][0][i] / 49.0;
     printf("  total (wave 0)               %7.0f cycles per step\n", tot);
   }
+#endif
   return 0;
 }
