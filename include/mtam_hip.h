@@ -196,6 +196,15 @@ int mtam_emb_scatter_add_bwd(const float *d_item_cat, const float *d_pos,
                              float *g_item, int item_rows, float *g_cat, int cat_rows,
                              float *g_pos, int pos_rows, float *g_user, int user_rows,
                              float *slot_sq_partial, void *stream);
+/* The same with the looked-up POSITION rows taken from the table through the ids (pos == NULL, pos_table given):
+ * for steps whose forward never wrote them out (mtam_seq_chain_gather_fwd). */
+int mtam_emb_scatter_add_bwd_postab(const float *d_item_cat, const float *d_pos, const float *item_cat,
+                                    const float *pos, const float *pos_table, const float *user,
+                                    const int32_t *item_ids, const int32_t *cat_ids, const int32_t *pos_ids,
+                                    const int32_t *user_ids, const int32_t *seq_len, int B, int L, float reg,
+                                    int with_user, float *g_item, int item_rows, float *g_cat, int cat_rows,
+                                    float *g_pos, int pos_rows, float *g_user, int user_rows,
+                                    float *slot_sq_partial, void *stream);
 
 /* ----------------------------------------------------------- time-aware GRU
  * dynamic_rnn(TimeAwareGRUCell_decay_new) + gather_indexes(seq_len - 2):
@@ -411,6 +420,25 @@ int mtam_score32_bwd(const float *E, const float *pred, const float *lse, const 
 int mtam_seq_chain_fwd(const float *ic, const float *W4, const float *pos, int R, const float *Wkv,
                        const float *bkv, int n_kv, const float *Wx, const float *bx, int n_x, float *zr, float *x,
                        float *kv, float *xproj, void *stream);
+/* The same launch with the four embedding lookups folded in (mtam_emb_gather_fwd + mtam_seq_chain_fwd as ONE
+ * kernel: SURVEY.md 2.1 K1 + K2): a workgroup gathers its stripe's [item | category] rows straight into the LDS
+ * operand of the first product and its position rows into the epilogue registers; the rows are never read back
+ * from HBM.  Also produced: the tf.nn.l2_loss partial sums (l2_partial[0 .. mtam_seq_chain_gather_partials(B, L));
+ * the rest of the n_l2 entries is zeroed), user_out [B, D], and -- ic_out != NULL, training -- a copy of the
+ * [item | category] rows [B*L, 2D] for the dense4emb weight gradient and the scatter-add's L2 term.  The
+ * position rows are not written (mtam_emb_scatter_add_bwd_postab reads them through the ids).  clear_a / clear_b:
+ * float ranges zeroed on the side (the step's gradient accumulators), as in mtam_emb_gather_fwd_clear.
+ * HBM bytes per sequence at L = 50, fp32: (3L+1)(512 + 4) table reads + ids, + L x 1,024 B of ic_out in training
+ * (evaluation: none), against (3L+1)(2 x 512 + 4) + L x 1,024 re-read for the two-kernel form. */
+int mtam_seq_chain_gather_partials(int B, int L);
+int mtam_seq_chain_gather_fwd(const float *item_table, int item_rows, const float *cat_table, int cat_rows,
+                              const float *pos_table, int pos_rows, const float *user_table, int user_rows,
+                              const int32_t *item_ids, const int32_t *cat_ids, const int32_t *pos_ids,
+                              const int32_t *user_ids, int B, int L, int with_user, const float *W4,
+                              const float *Wkv, const float *bkv, int n_kv, const float *Wx, const float *bx,
+                              int n_x, float *ic_out, float *user_out, float *l2_partial, int n_l2, float *zr,
+                              float *x, float *kv, float *xproj, float *clear_a, size_t n_clear_a, float *clear_b,
+                              size_t n_clear_b, void *stream);
 
 /* ------------------------------------------------------------------ top-K
  * tf.nn.top_k (Model/base_model.py:196-200): for every row the k largest

@@ -370,19 +370,32 @@ class TimeAwarePath(object):
         predict_behavior_emb (slab-wise evaluation scores the catalog itself)."""
         B, R, L, NB, H = bt.B, bt.R, self.L, self.NB, self.H
         fd, T, cfg = bt.feed, self.tables, self.cfg
-        ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
-                           fd["category_list"], fd["position_list"], fd["user_id"], B, L, 1,
-                           bt.ic, bt.pos, bt.user, bt.l2_partial,
-                           # a training step's first kernel also clears its gradient accumulators
-                           clear=(self.zero_prefix, bt.d_clear if cfg["keys"] == "gru" else bt.d_pred.view(-1))
-                           if training else (), item16=self.item16)
+        # a training step's first kernel also clears its gradient accumulators
+        clear = (self.zero_prefix, bt.d_clear if cfg["keys"] == "gru" else bt.d_pred.view(-1)) if training else ()
         keys = bt.hs if cfg["keys"] == "gru" else bt.x        # user_history: what the decoder attends over
         kv_from_x = cfg["attention"] and cfg["keys"] == "x"    # keys/values of every block (before the GRU)
         # dense4emb, the K/V projection and the GRU's input projection in ONE launch (a 32-row stripe of x
         # stays on its CU; 16-byte stores): 25.5 us against 35.4 us as three GEMMs at 6,400 rows.
         # MTAM_SEQ_CHAIN=0 keeps the three GEMMs.
         chain = cfg["gru"] != "seqrec" and os.environ.get("MTAM_SEQ_CHAIN", "1") != "0"
-        if chain:
+        # ... and the four embedding lookups folded into the same launch (fp32 item rows): the looked-up rows go
+        # straight into the first product's LDS operand; the position rows are never written, the [item | category]
+        # rows only in training (dense4emb's weight gradient reads them).  MTAM_FUSED_GATHER=0 keeps the gather kernel.
+        bt.fused_gather = chain and self.item16 is None and os.environ.get("MTAM_FUSED_GATHER", "1") != "0"
+        if bt.fused_gather:
+            ops.seq_chain_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
+                                     fd["category_list"], fd["position_list"], fd["user_id"], B, L, 1,
+                                     self.seg("dense4emb/w"),
+                                     self.seg("kv/w") if kv_from_x else None, self.seg("kv/b") if kv_from_x else None,
+                                     self.seg("gru/wx"), self.seg("gru/bx"), bt.ic if training else None, bt.user,
+                                     bt.l2_partial, bt.zr, bt.x, bt.kv if kv_from_x else None, bt.xproj, clear=clear)
+        else:
+            ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
+                               fd["category_list"], fd["position_list"], fd["user_id"], B, L, 1,
+                               bt.ic, bt.pos, bt.user, bt.l2_partial, clear=clear, item16=self.item16)
+        if bt.fused_gather:
+            pass
+        elif chain:
             ops.seq_chain_fwd(bt.ic, self.seg("dense4emb/w"), bt.pos, R,
                               self.seg("kv/w") if kv_from_x else None, self.seg("kv/b") if kv_from_x else None,
                               self.seg("gru/wx"), self.seg("gru/bx"), bt.zr, bt.x, bt.kv if kv_from_x else None,
@@ -545,10 +558,11 @@ class TimeAwarePath(object):
             ops.colsum_atomic_multi(chunk)
         # tables: sparse rows on top of the dense item gradient
         slot_part = part[self.nb_dense + self.nb_item:]
-        ops.emb_scatter_add_bwd(bt.d_ic, bt.d_x, bt.ic, bt.pos, bt.user, fd["item_list"], fd["category_list"],
-                                fd["position_list"], fd["user_id"], fd["seq_length"], B, L, self.reg, 1,
-                                self.g_tab["item"], self.g_tab["category"], self.g_tab["position"],
-                                self.g_tab["user"], slot_part)
+        fused = getattr(bt, "fused_gather", False)         # the position rows were not written out: read by id
+        ops.emb_scatter_add_bwd(bt.d_ic, bt.d_x, bt.ic, None if fused else bt.pos, bt.user, fd["item_list"],
+                                fd["category_list"], fd["position_list"], fd["user_id"], fd["seq_length"], B, L,
+                                self.reg, 1, self.g_tab["item"], self.g_tab["category"], self.g_tab["position"],
+                                self.g_tab["user"], slot_part, pos_table=T["position"] if fused else None)
 
     # ------------------------------------------------------------------ update
     def clip_and_apply(self, bt):

@@ -37,6 +37,12 @@ SIGNATURES = {
     "mtam_emb_scatter_partials": (c_int, [c_int, c_int]),
     "mtam_emb_scatter_add_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
                                          P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
+    "mtam_emb_scatter_add_bwd_postab": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
+                                                P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
+    "mtam_seq_chain_gather_partials": (c_int, [c_int, c_int]),
+    "mtam_seq_chain_gather_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
+                                          P, P, P, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P, P, c_size_t, P,
+                                          c_size_t, P]),
     "mtam_tagru_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "mtam_tagru_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
     "mtam_tagru_seqrec_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),

@@ -136,6 +136,9 @@ struct ScatterArgs {
   float *sq_partial;
   int n_rm, n_tr, n_user;      // chunks: row-major (item, category), transposed (position), user
   int n_partials;
+  // non-NULL: the looked-up position rows were never written out (the gather lives inside the forward's first
+  // GEMM kernel, mtam_seq_chain_gather_fwd): the L2 term of a position slot reads its table row through the id
+  const float *pos_table;
 };
 
 // Scatter-add with a per-workgroup duplicate pre-reduction.
@@ -200,7 +203,8 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
       float *gp = p.g_pos + (size_t)clamp_id(p.pos_ids[r], p.pos_rows) * D;
       for (int e = lane; e < D; e += 64) {
         const float vi = p.ic[(size_t)r * 2 * D + e], vc = p.ic[(size_t)r * 2 * D + D + e];
-        const float vp = p.pos[(size_t)r * D + e];
+        const float vp = p.pos_table ? p.pos_table[(size_t)clamp_id(p.pos_ids[r], p.pos_rows) * D + e]
+                                     : p.pos[(size_t)r * D + e];
         atomicAdd(gi + e, w * vi);
         atomicAdd(gc + e, w * vc);
         atomicAdd(gp + e, w * vp);
@@ -260,9 +264,11 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
     sl[k] = p.seq_len[min(bb, p.B - 1)];
   }
   float v[SPH][4], dv[SPH][4];
+  const bool pos_from_table = table == 2 && p.pos_table != nullptr;      // block-uniform
 #pragma unroll
   for (int k = 0; k < SPH; ++k) {
-    const float *e = e_base + (size_t)max(cand[k], 0) * stride + li;
+    const float *e = pos_from_table ? p.pos_table + (size_t)clamp_id(id[k], rows) * D + li
+                                    : e_base + (size_t)max(cand[k], 0) * stride + li;
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[k][q] = e[32 * q];
   }
@@ -444,15 +450,31 @@ extern "C" int mtam_emb_scatter_add_bwd(const float *d_item_cat, const float *d_
                                         void *stream) {
   MTAM_CHECK_ARG(B > 0 && L > 0, "emb_scatter: B and L must be positive");
   MTAM_CHECK_ARG((long)B * L * 3 + B < 0x3fffffffL, "emb_scatter: batch too large");
-  MTAM_CHECK_ARG(d_item_cat && d_pos && item_cat && pos && user, "emb_scatter: null gradient or gathered rows");
+  return mtam_emb_scatter_add_bwd_postab(d_item_cat, d_pos, item_cat, pos, nullptr, user, item_ids, cat_ids, pos_ids,
+                                         user_ids, seq_len, B, L, reg, with_user, g_item, item_rows, g_cat, cat_rows,
+                                         g_pos, pos_rows, g_user, user_rows, slot_sq_partial, stream);
+}
+
+extern "C" int mtam_emb_scatter_add_bwd_postab(const float *d_item_cat, const float *d_pos, const float *item_cat,
+                                               const float *pos, const float *pos_table, const float *user,
+                                               const int32_t *item_ids, const int32_t *cat_ids,
+                                               const int32_t *pos_ids, const int32_t *user_ids,
+                                               const int32_t *seq_len, int B, int L, float reg, int with_user,
+                                               float *g_item, int item_rows, float *g_cat, int cat_rows, float *g_pos,
+                                               int pos_rows, float *g_user, int user_rows, float *slot_sq_partial,
+                                               void *stream) {
+  MTAM_CHECK_ARG(B > 0 && L > 0, "emb_scatter: B and L must be positive");
+  MTAM_CHECK_ARG((long)B * L * 3 + B < 0x3fffffffL, "emb_scatter: batch too large");
+  MTAM_CHECK_ARG(d_item_cat && d_pos && item_cat && (pos || pos_table) && user,
+                 "emb_scatter: null gradient or gathered rows");
   MTAM_CHECK_ARG(item_ids && cat_ids && pos_ids && user_ids && seq_len, "emb_scatter: null ids");
   MTAM_CHECK_ARG(g_item && g_cat && g_pos && (g_user || !with_user) && slot_sq_partial, "emb_scatter: null output");
   MTAM_CHECK_ARG(item_rows > 0 && cat_rows > 0 && pos_rows > 0 && user_rows > 0, "emb_scatter: empty table");
-  ScatterArgs a{d_item_cat, d_pos, item_cat, pos, user, item_ids, cat_ids, pos_ids, user_ids, seq_len,
+  ScatterArgs a{d_item_cat, d_pos, item_cat, pos ? pos : pos_table, user, item_ids, cat_ids, pos_ids, user_ids, seq_len,
                 B, L, with_user, reg, g_item, g_cat, g_pos, g_user,
                 item_rows, cat_rows, pos_rows, user_rows, slot_sq_partial,
                 scatter_rm_chunks(B, L), scatter_tr_chunks(B, L), with_user ? scatter_user_chunks(B) : 0,
-                mtam_emb_scatter_partials(B, L)};
+                mtam_emb_scatter_partials(B, L), pos ? nullptr : pos_table};
   hipLaunchKernelGGL(emb_scatter_kernel, dim3(2 * a.n_rm + a.n_tr + a.n_user + 1), dim3(SCATTER_THREADS), 0,
                      static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("emb_scatter");

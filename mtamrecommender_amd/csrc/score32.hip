@@ -163,6 +163,9 @@ struct BwdArgs {
   int V, Bt, slabs_per_wg;
   float scale;
   float *d_pred, *dE, *sq_partial;
+  int lab;      // developer switches (MTAM_SCORE32_LAB, tools/score32_time.py): parts of x3::bwd_pc_kernel cut out to
+                // time the rest -- 1: no dE stores, 2: no G[v][b] element writes, 4: no E^T gathers for d_pred,
+                // 8: no exp.  0 in every product run.
 };
 
 template <bool RMW>
@@ -571,6 +574,228 @@ __global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
   }
 }
 
+// ---- the same pass with the work cut by ROLE instead of by tile: 8 waves, two per SIMD.
+// bwd_kernel above keeps one wave per SIMD busy with everything in turn -- split E, scores, exp + split G, two
+// products -- and its 356 registers per lane allow no second workgroup on the CU: the matrix pipe idles through
+// every VALU / LDS stretch (6.4 ms at 10 M rows against 2.35 ms of MFMA issue).  Here waves 0..3 PRODUCE (split the
+// next slab, score it, turn the scores into the three G images) while waves 4..7, their SIMD partners, CONSUME
+// (dE and d_pred of the current slab): vector work of one role runs beside matrix work of the other.
+//   phase a   P: split E(s + 1) -> e[next]                 C: dE(s)            <- g
+//   phase b   P: scores(s + 1)  <- e[next]                  C: d_pred(s), blocks 0, 1  <- gt[cur], e[cur]
+//   phase c   P: G(s + 1) -> g, gt[next]                    C: d_pred(s), blocks 2, 3  <- gt[cur], e[cur]
+// E images and G^T images are double-buffered, G single (140 KB of LDS); three barriers per slab, as before.
+constexpr int T_PITCH = 36;             // per consumer wave: a 32 x 32 fp32 tile on its way out, rows 36 floats apart
+constexpr int PC_SCRATCH = 4 * 32 * T_PITCH * 4;
+constexpr int PC_LDS = 2 * 3 * E_IMG + 3 * G_IMG + 2 * 3 * GT_IMG + PC_SCRATCH;      // 158,208 B
+
+template <bool RMW>
+__global__ __launch_bounds__(512) void bwd_pc_kernel(BwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char *const e_buf = lds;                                   // [2][3][E_IMG]
+  unsigned char *const g_img = lds + 2 * 3 * E_IMG;                   // [3][G_IMG]
+  unsigned char *const gt_buf = g_img + 3 * G_IMG;                    // [2][3][GT_IMG]
+  float *const t_scratch = reinterpret_cast<float *>(gt_buf + 2 * 3 * GT_IMG);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const bool producer = wave < 4;
+  const int w = wave & 3, ptid = tid & 255;
+  const int V = p.V;
+  const int nslab = (V + SLAB - 1) / SLAB;
+  const int slab0 = min((int)blockIdx.x * p.slabs_per_wg, nslab), slab1 = min(nslab, slab0 + p.slabs_per_wg);
+  const int n = slab1 - slab0;
+  if (n <= 0) {                      // (a workgroup past the end of the catalog: nothing to add, nothing to sum)
+    if (!producer && p.sq_partial && lane == 0) p.sq_partial[(size_t)blockIdx.x * 4 + w] = 0.f;
+    return;
+  }
+
+  if (producer) {
+    // ---------------------------------------------------------------- producer waves
+    const int bcol = 32 * w + r;      // the batch row (of the tile) whose scores sit on this lane
+    const bool valid_b = bcol < p.Bt;
+    const int brow = min(bcol, p.Bt - 1);
+    const float c_b = valid_b ? fmaf(-p.lse[brow], L2E, log2f(p.scale)) : -INFINITY;
+    const int t_b = valid_b ? min(max(p.target[brow], 0), V - 1) : -1;
+    Tri p1[8];
+    load_pred_rows(p1, p.P + (size_t)brow * D, h);
+    unsigned char *const g_wr = g_img + (4 * h) * G_PITCH + (32 * w + r) * 2;
+    Stage st;
+    f32x16 acc;
+    auto make_g = [&](int sl, unsigned char *gt_img) {      // scores in acc -> G(sl), split, both orientations
+      unsigned char *const gt_wr = gt_img + (32 * w + r) * GT_PITCH + (4 * h) * 2;
+      const int vbase = sl * SLAB;
+      const int vlim = (vbase + SLAB <= V) ? 0x7fffffff : V;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        bf16x4 gq[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 8 * q4 + i;
+          const int v = vbase + row + 4 * h;
+          float g = ((p.lab & 8) ? acc[4 * q4 + i] * 1e-3f : fast_exp2(fmaf(acc[4 * q4 + i], L2E, c_b))) -
+                    ((v == t_b) ? p.scale : 0.f);
+          g = (v < vlim) ? g : 0.f;
+          __bf16 a, b, c;
+          split3(g, a, b, c);
+          gq[0][i] = a; gq[1][i] = b; gq[2][i] = c;
+          if (!(p.lab & 2)) {
+            *reinterpret_cast<__bf16 *>(g_wr + row * G_PITCH) = a;
+            *reinterpret_cast<__bf16 *>(g_wr + G_IMG + row * G_PITCH) = b;
+            *reinterpret_cast<__bf16 *>(g_wr + 2 * G_IMG + row * G_PITCH) = c;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4 *>(gt_wr + t * GT_IMG + (8 * q4) * 2) = gq[t];
+      }
+    };
+    // prologue: slab 0 scored and turned into G before the first consumer phase
+    stage_load(st, p.E, slab0 * SLAB, V, ptid);
+    stage_store_split(st, e_buf, ptid);
+    if (n > 1) stage_load(st, p.E, (slab0 + 1) * SLAB, V, ptid);
+    __syncthreads();
+    acc = slab_scores(e_buf, p1, r, h);
+    make_g(slab0, gt_buf);
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+      const bool more = i + 1 < n;
+      unsigned char *const e_next = e_buf + ((i + 1) & 1) * 3 * E_IMG;
+      // phase a: split slab i + 1 (its fp32 rows arrived during the previous phases), fetch slab i + 2
+      if (more) stage_store_split(st, e_next, ptid);
+      if (i + 2 < n) stage_load(st, p.E, (slab0 + i + 2) * SLAB, V, ptid);
+      __syncthreads();
+      // phase b: scores of slab i + 1
+      if (more) acc = slab_scores(e_next, p1, r, h);
+      __syncthreads();
+      // phase c: G of slab i + 1
+      if (more) make_g(slab0 + i + 1, gt_buf + ((i + 1) & 1) * 3 * GT_IMG);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ consumer waves
+  const int dcol = 32 * w + r;        // this lane's output column in both backward products
+  Tri p2[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = p.P[(size_t)min(16 * s + 8 * h + j, p.Bt - 1) * D + dcol];
+    p2[s] = split8(x);
+  }
+  f32x16 dp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dp[i] = f32x16{0.f};
+  float sq = 0.f;
+  const unsigned char *const g_rd = g_img + r * G_PITCH + 16 * h;
+  auto dpred_blocks = [&](const unsigned char *e_img, const unsigned char *gt_img, int m0) {
+    const unsigned char *const gt_rd = gt_img + r * GT_PITCH + 16 * h;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Tri bfrag;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (p.lab & 4) {
+          bfrag.t[t] = *reinterpret_cast<const bf16x8 *>(e_img + t * E_IMG + r * E_PITCH + 32 * s + 16 * h);
+          continue;
+        }
+        uint16_t u[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          u[j] = *reinterpret_cast<const uint16_t *>(e_img + t * E_IMG + (16 * s + 8 * h + j) * E_PITCH + dcol * 2);
+        const u32x4 pk = {(uint32_t)u[0] | ((uint32_t)u[1] << 16), (uint32_t)u[2] | ((uint32_t)u[3] << 16),
+                          (uint32_t)u[4] | ((uint32_t)u[5] << 16), (uint32_t)u[6] | ((uint32_t)u[7] << 16)};
+        bfrag.t[t] = __builtin_bit_cast(bf16x8, pk);
+      }
+#pragma unroll
+      for (int mblk = m0; mblk < m0 + 2; ++mblk) {
+        Tri a;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          a.t[t] = *reinterpret_cast<const bf16x8 *>(gt_rd + t * GT_IMG + (32 * mblk) * GT_PITCH + 32 * s);
+        dp[mblk] = mfma6(a, bfrag, dp[mblk]);
+      }
+    }
+  };
+  __syncthreads();       // (producer prologue: slab 0 staged)
+  __syncthreads();       // (producer prologue: G of slab 0 in place)
+  for (int i = 0; i < n; ++i) {
+    const int vbase = (slab0 + i) * SLAB;
+    const bool full = vbase + SLAB <= V;
+    const unsigned char *const e_cur = e_buf + (i & 1) * 3 * E_IMG;
+    const unsigned char *const gt_cur = gt_buf + (i & 1) * 3 * GT_IMG;
+    // phase a: dE[v][d] = sum_b G[v][b] pred[b][d]   (this wave: columns d = 32 w ..)
+    {
+      f32x16 acc = {0.f};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        Tri a;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a.t[t] = *reinterpret_cast<const bf16x8 *>(g_rd + t * G_IMG + 32 * s);
+        acc = mfma6(a, p2[s], acc);
+      }
+      float *const out = p.dE + ((size_t)vbase + 4 * h) * D + dcol;
+      if (RMW) {
+        float old[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          old[q] = out[(long)min((q & 3) + 8 * (q >> 2), V - 1 - vbase - 4 * h) * D];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += old[q];
+      }
+      // The tile has its column on the lane: stored as it lies that is 16 four-byte stores of 128-byte segments per
+      // lane (store ISSUE, 0.6 ms of the pass at 10 M rows).  Through a wave-private LDS scratch it leaves as four
+      // 16-byte stores per lane (8 rows x 128 B per wave instruction).
+      if (full && !RMW) {
+        float *const sc = t_scratch + w * (32 * T_PITCH);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          sq = fmaf(acc[q], acc[q], sq);
+          sc[((q & 3) + 8 * (q >> 2) + 4 * h) * T_PITCH + r] = acc[q];
+        }
+        if (!(p.lab & 1)) {
+#pragma unroll
+          for (int i4 = 0; i4 < 4; ++i4) {
+            const int idx = i4 * 64 + lane, row = idx >> 3, c4 = idx & 7;
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(sc + row * T_PITCH + 4 * c4);
+            *reinterpret_cast<f32x4 *>(p.dE + ((size_t)vbase + row) * D + 32 * w + 4 * c4) = t;
+          }
+        }
+      } else if (full) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          sq = fmaf(acc[q], acc[q], sq);
+          out[(size_t)((q & 3) + 8 * (q >> 2)) * D] = acc[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = (q & 3) + 8 * (q >> 2);
+          if (vbase + row + 4 * h < V) {
+            sq = fmaf(acc[q], acc[q], sq);
+            out[(size_t)row * D] = acc[q];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // phases b, c: d_pred[b][d] += sum_v G[v][b] E[v][d]   (this wave: columns d = 32 w .., two 32-row blocks each)
+    dpred_blocks(e_cur, gt_cur, 0);
+    __syncthreads();
+    dpred_blocks(e_cur, gt_cur, 2);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mblk = 0; mblk < 4; ++mblk)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int b = 32 * mblk + acc_row(q, h);
+      if (b < p.Bt) atomicAdd(p.d_pred + b * D + dcol, dp[mblk][q]);
+    }
+  if (p.sq_partial) {
+    sq = wave_sum(sq);
+    if (lane == 0) p.sq_partial[(size_t)blockIdx.x * 4 + w] = sq;
+  }
+}
+
 }  // namespace x3
 
 // which form a catalog of V rows is scored with: the split-bf16 kernels from MTAM_SCORE32_SPLIT_MIN_ROWS rows on
@@ -581,6 +806,17 @@ bool use_split(int V) {
     return e ? atol(e) : 65536L;
   }();
   return min_rows > 0 && V >= min_rows;
+}
+int lab_bits() {
+  const char *e = getenv("MTAM_SCORE32_LAB");      // read at every call: the lab flips it between timings
+  return e ? atoi(e) : 0;
+}
+bool use_pc() {
+  static const bool on = [] {
+    const char *e = getenv("MTAM_SCORE32_PC");
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }
 
 int slabs_of(int V) { return (V + SLAB - 1) / SLAB; }
@@ -597,12 +833,16 @@ int max_wgs() {
   return v;
 }
 int chunks_of(int V) { return max(1, min(slabs_of(V), max_wgs())); }
+// the forward (lse) pass has nothing to flush: up to 2,048 ranges, so that three workgroups per CU keep loads in flight
+int lse_chunks_of(int V) { return max(1, min(slabs_of(V), 2048)); }
+int lse_slabs_per_wg_of(int V) { return (slabs_of(V) + lse_chunks_of(V) - 1) / lse_chunks_of(V); }
+int lse_grid_of(int V) { return (slabs_of(V) + lse_slabs_per_wg_of(V) - 1) / lse_slabs_per_wg_of(V); }
 int slabs_per_wg_of(int V) { return (slabs_of(V) + chunks_of(V) - 1) / chunks_of(V); }
 int grid_of(int V) { return (slabs_of(V) + slabs_per_wg_of(V) - 1) / slabs_per_wg_of(V); }
 
 }  // namespace
 
-extern "C" int mtam_score32_partials(int B, int V) { return B * grid_of(V) * 2; }
+extern "C" int mtam_score32_partials(int B, int V) { return B * lse_grid_of(V) * 2; }
 extern "C" int mtam_score32_sq_partials(int V) { return grid_of(V) * 4; }
 
 extern "C" int mtam_score32_lse(const float *E, const float *pred, const int32_t *target, int B, int V,
@@ -611,13 +851,13 @@ extern "C" int mtam_score32_lse(const float *E, const float *pred, const int32_t
   MTAM_CHECK_ARG(B > 0 && V > 0 && V < 0x7fffff00 && (B + BT - 1) / BT <= 65535, "score32_lse: bad shape B=%d V=%d", B, V);
   MTAM_CHECK_ARG(mtam_aligned16(E) && mtam_aligned16(pred), "score32_lse: operands must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int grid = grid_of(V);
+  const int grid = lse_grid_of(V);
   if (use_split(V))
     hipLaunchKernelGGL(x3::lse_kernel, dim3(grid, (B + BT - 1) / BT), dim3(256), 0, s, E, pred, V, B,
-                       slabs_per_wg_of(V), partial);
+                       lse_slabs_per_wg_of(V), partial);
   else
     hipLaunchKernelGGL(score32_lse_kernel, dim3(grid, (B + BT - 1) / BT), dim3(256), 0, s, E, pred, V, B,
-                       slabs_per_wg_of(V), partial);
+                       lse_slabs_per_wg_of(V), partial);
   hipLaunchKernelGGL(score32_finish_kernel, dim3(B), dim3(256), 0, s, E, pred, target, V, grid, partial, lse, ce);
   MTAM_CHECK_LAUNCH("score32_lse");
   return MTAM_OK;
@@ -638,6 +878,12 @@ extern "C" int mtam_score32_bwd(const float *E, const float *pred, const float *
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(x3::bwd_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, x3::BWD_LDS);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(x3::bwd_pc_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, x3::PC_LDS);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(x3::bwd_pc_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, x3::PC_LDS);
       MTAM_CHECK_ARG(e == hipSuccess, "score32_bwd: cannot reserve %d bytes of LDS: %s", x3::BWD_LDS,
                      hipGetErrorString(e));
       attr_set = true;
@@ -648,8 +894,12 @@ extern "C" int mtam_score32_bwd(const float *E, const float *pred, const float *
   for (int tile = 0; tile < ntile; ++tile) {
     const long b0 = (long)tile * BT;
     BwdArgs a{E, pred + b0 * D, lse + b0, target + b0, V, (int)min((long)BT, B - b0), slabs_per_wg_of(V), scale,
-              d_pred + b0 * D, dE, tile == ntile - 1 ? sq_partial : nullptr};
-    if (split && tile == 0)
+              d_pred + b0 * D, dE, tile == ntile - 1 ? sq_partial : nullptr, lab_bits()};
+    if (split && use_pc() && tile == 0)
+      hipLaunchKernelGGL(x3::bwd_pc_kernel<false>, dim3(grid_of(V)), dim3(512), x3::PC_LDS, st, a);
+    else if (split && use_pc())
+      hipLaunchKernelGGL(x3::bwd_pc_kernel<true>, dim3(grid_of(V)), dim3(512), x3::PC_LDS, st, a);
+    else if (split && tile == 0)
       hipLaunchKernelGGL(x3::bwd_kernel<false>, dim3(grid_of(V)), dim3(256), x3::BWD_LDS, st, a);
     else if (split)
       hipLaunchKernelGGL(x3::bwd_kernel<true>, dim3(grid_of(V)), dim3(256), x3::BWD_LDS, st, a);

@@ -50,8 +50,21 @@ struct ChainArgs {
   const float *Wx, *bx;
   int n_x;
   float *zr, *x, *kv, *xproj;
+  // GATHER: the stripe's [item | category] and position rows come straight from the tables (the four
+  // tf.nn.embedding_lookup of Embedding/Behavior_embedding_time_aware_attention.py:68-95 folded in, with the
+  // tf.nn.l2_loss sums of Model/base_model.py:302-307): `ic` / `pos` above are not read
+  const float *item_table, *cat_table, *pos_table, *user_table;
+  int item_rows, cat_rows, pos_rows, user_rows;
+  const int32_t *item_ids, *cat_ids, *pos_ids, *user_ids;
+  int B, with_user, n_l2;
+  float *ic_out, *user_out, *l2_partial;     // ic_out may be NULL (evaluation: nothing reads the rows again)
+  float4 *clear_a, *clear_b;                 // the step's gradient accumulators, cleared on the side
+  size_t n_a4, n_b4;
 };
 
+__device__ __forceinline__ int clamp_row(int id, int rows) { return min(max(id, 0), rows - 1); }
+
+template <bool GATHER>
 __global__ __launch_bounds__(256) void seq_chain_fwd_kernel(ChainArgs p) {
   __shared__ __attribute__((aligned(16))) float a_lds[ROWS * A_PITCH];
   __shared__ __attribute__((aligned(16))) float x_lds[ROWS * X_PITCH];
@@ -63,13 +76,35 @@ __global__ __launch_bounds__(256) void seq_chain_fwd_kernel(ChainArgs p) {
   float b1[D];
 #pragma unroll
   for (int s = 0; s < D; ++s) b1[s] = p.W4[(size_t)(s + D * h) * D + 32 * w + r];
+  float sq = 0.f;                          // GATHER: this thread's share of sum x^2 over the looked-up rows
   {
     f32x4 v[8];
+    if (GATHER) {
+      // a thread's 8 pieces are the same 16 bytes (column tid & 63) of 8 rows: all from one table
+      const bool is_cat = (tid & 63) >= 32;
+      const int32_t *ids = is_cat ? p.cat_ids : p.item_ids;
+      const float *tab = is_cat ? p.cat_table : p.item_table;
+      const int nrows = is_cat ? p.cat_rows : p.item_rows, off = ((tid & 63) - (is_cat ? 32 : 0)) * 4;
+      int id[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = i * 256 + tid;
-      const long row = min(row0 + (c >> 6), (long)R - 1);
-      v[i] = *reinterpret_cast<const f32x4 *>(p.ic + row * (2 * D) + (c & 63) * 4);
+      for (int i = 0; i < 8; ++i) id[i] = ids[min(row0 + 4 * i + w, (long)R - 1)];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4 *>(tab + (size_t)clamp_row(id[i], nrows) * D + off);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long row = row0 + 4 * i + w;
+        if (row < R) {
+          sq += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+          if (p.ic_out) *reinterpret_cast<f32x4 *>(p.ic_out + row * (2 * D) + (tid & 63) * 4) = v[i];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = i * 256 + tid;
+        const long row = min(row0 + (c >> 6), (long)R - 1);
+        v[i] = *reinterpret_cast<const f32x4 *>(p.ic + row * (2 * D) + (c & 63) * 4);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -80,10 +115,45 @@ __global__ __launch_bounds__(256) void seq_chain_fwd_kernel(ChainArgs p) {
   }
   // position rows of this lane's output elements (column 32 w + r, rows (q & 3) + 8 (q >> 2) + 4 h)
   float pv[16];
+  if (GATHER) {
+    int pid[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const long row = min(row0 + (q & 3) + 8 * (q >> 2) + 4 * h, (long)R - 1);
-    pv[q] = p.pos[row * D + 32 * w + r];
+    for (int q = 0; q < 16; ++q) pid[q] = p.pos_ids[min(row0 + (q & 3) + 8 * (q >> 2) + 4 * h, (long)R - 1)];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pv[q] = p.pos_table[(size_t)clamp_row(pid[q], p.pos_rows) * D + 32 * w + r];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (row0 + (q & 3) + 8 * (q >> 2) + 4 * h < R) sq = fmaf(pv[q], pv[q], sq);
+    // the user rows of 32 samples ride with the first ceil(B / 32) stripes (only their sum of squares and, for
+    // the scatter-add's L2 term, a copy are needed)
+    if ((long)blockIdx.x * 32 < p.B) {
+      int uid[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) uid[i] = p.user_ids[min((int)blockIdx.x * 32 + 8 * i + (tid >> 5), p.B - 1)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ub = blockIdx.x * 32 + 8 * i + (tid >> 5);
+        const f32x4 u = *reinterpret_cast<const f32x4 *>(p.user_table + (size_t)clamp_row(uid[i], p.user_rows) * D +
+                                                        (tid & 31) * 4);
+        if (ub < p.B) {
+          *reinterpret_cast<f32x4 *>(p.user_out + (size_t)ub * D + (tid & 31) * 4) = u;
+          if (p.with_user) sq += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+        }
+      }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) p.l2_partial[blockIdx.x * 4 + w] = sq;
+    const size_t stride = (size_t)gridDim.x * 256, g0 = (size_t)blockIdx.x * 256 + tid;
+    for (size_t i = (size_t)gridDim.x * 4 + g0; i < (size_t)p.n_l2; i += stride) p.l2_partial[i] = 0.f;   // unused tail
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = g0; i < p.n_a4; i += stride) p.clear_a[i] = z;
+    for (size_t i = g0; i < p.n_b4; i += stride) p.clear_b[i] = z;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const long row = min(row0 + (q & 3) + 8 * (q >> 2) + 4 * h, (long)R - 1);
+      pv[q] = p.pos[row * D + 32 * w + r];
+    }
   }
   __syncthreads();
 
@@ -170,8 +240,54 @@ extern "C" int mtam_seq_chain_fwd(const float *ic, const float *W4, const float 
   MTAM_CHECK_ARG(n_kv >= 0 && n_kv % 32 == 0 && n_x > 0 && n_x % 32 == 0, "seq_chain_fwd: widths must be multiples of 32");
   MTAM_CHECK_ARG(n_kv == 0 || (Wkv && bkv && kv), "seq_chain_fwd: n_kv > 0 needs Wkv, bkv and kv");
   MTAM_CHECK_ARG(mtam_aligned16(ic), "seq_chain_fwd: ic must be 16-byte aligned");
-  ChainArgs a{ic, W4, pos, R, Wkv, bkv, n_kv, Wx, bx, n_x, zr, x, kv, xproj};
-  hipLaunchKernelGGL(seq_chain_fwd_kernel, dim3((R + ROWS - 1) / ROWS), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  ChainArgs a{};
+  a.ic = ic; a.W4 = W4; a.pos = pos; a.R = R; a.Wkv = Wkv; a.bkv = bkv; a.n_kv = n_kv; a.Wx = Wx; a.bx = bx; a.n_x = n_x;
+  a.zr = zr; a.x = x; a.kv = kv; a.xproj = xproj;
+  hipLaunchKernelGGL(seq_chain_fwd_kernel<false>, dim3((R + ROWS - 1) / ROWS), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("seq_chain_fwd");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_seq_chain_gather_partials(int B, int L) { return 4 * ((B * L + ROWS - 1) / ROWS); }
+
+extern "C" int mtam_seq_chain_gather_fwd(const float *item_table, int item_rows, const float *cat_table, int cat_rows,
+                                         const float *pos_table, int pos_rows, const float *user_table,
+                                         int user_rows, const int32_t *item_ids, const int32_t *cat_ids,
+                                         const int32_t *pos_ids, const int32_t *user_ids, int B, int L, int with_user,
+                                         const float *W4, const float *Wkv, const float *bkv, int n_kv,
+                                         const float *Wx, const float *bx, int n_x, float *ic_out, float *user_out,
+                                         float *l2_partial, int n_l2, float *zr, float *x, float *kv, float *xproj,
+                                         float *clear_a, size_t n_clear_a, float *clear_b, size_t n_clear_b,
+                                         void *stream) {
+  MTAM_CHECK_ARG(B > 0 && L > 0 && (long)B * L < 0x3fffffffL, "seq_chain_gather_fwd: bad batch shape");
+  const int R = B * L;
+  MTAM_CHECK_ARG(item_table && cat_table && pos_table && user_table && item_ids && cat_ids && pos_ids && user_ids,
+                 "seq_chain_gather_fwd: null table or ids");
+  MTAM_CHECK_ARG(item_rows > 0 && cat_rows > 0 && pos_rows > 0 && user_rows > 0, "seq_chain_gather_fwd: empty table");
+  MTAM_CHECK_ARG(W4 && Wx && bx && zr && x && xproj && user_out && l2_partial, "seq_chain_gather_fwd: null argument");
+  MTAM_CHECK_ARG(n_kv >= 0 && n_kv % 32 == 0 && n_x > 0 && n_x % 32 == 0,
+                 "seq_chain_gather_fwd: widths must be multiples of 32");
+  MTAM_CHECK_ARG(n_kv == 0 || (Wkv && bkv && kv), "seq_chain_gather_fwd: n_kv > 0 needs Wkv, bkv and kv");
+  MTAM_CHECK_ARG(n_l2 >= mtam_seq_chain_gather_partials(B, L), "seq_chain_gather_fwd: l2_partial too short");
+  MTAM_CHECK_ARG((B + 31) / 32 <= (R + ROWS - 1) / ROWS, "seq_chain_gather_fwd: L must be at least 1");
+  MTAM_CHECK_ARG(mtam_aligned16(item_table) && mtam_aligned16(cat_table) && mtam_aligned16(user_table) &&
+                     mtam_aligned16(ic_out) && mtam_aligned16(user_out),
+                 "seq_chain_gather_fwd: tables and row outputs must be 16-byte aligned");
+  MTAM_CHECK_ARG(n_clear_a % 4 == 0 && n_clear_b % 4 == 0 && mtam_aligned16(clear_a) && mtam_aligned16(clear_b),
+                 "seq_chain_gather_fwd: clear ranges must be 16-byte aligned multiples of 4 floats");
+  ChainArgs a{};
+  a.W4 = W4; a.R = R; a.Wkv = Wkv; a.bkv = bkv; a.n_kv = n_kv; a.Wx = Wx; a.bx = bx; a.n_x = n_x;
+  a.zr = zr; a.x = x; a.kv = kv; a.xproj = xproj;
+  a.item_table = item_table; a.cat_table = cat_table; a.pos_table = pos_table; a.user_table = user_table;
+  a.item_rows = item_rows; a.cat_rows = cat_rows; a.pos_rows = pos_rows; a.user_rows = user_rows;
+  a.item_ids = item_ids; a.cat_ids = cat_ids; a.pos_ids = pos_ids; a.user_ids = user_ids;
+  a.B = B; a.with_user = with_user; a.n_l2 = n_l2;
+  a.ic_out = ic_out; a.user_out = user_out; a.l2_partial = l2_partial;
+  a.clear_a = reinterpret_cast<float4 *>(clear_a); a.n_a4 = clear_a ? n_clear_a / 4 : 0;
+  a.clear_b = reinterpret_cast<float4 *>(clear_b); a.n_b4 = clear_b ? n_clear_b / 4 : 0;
+  hipLaunchKernelGGL(seq_chain_fwd_kernel<true>, dim3((R + ROWS - 1) / ROWS), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  MTAM_CHECK_LAUNCH("seq_chain_gather_fwd");
   return MTAM_OK;
 }

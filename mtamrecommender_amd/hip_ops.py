@@ -121,8 +121,17 @@ def emb_scatter_partials(B, L):
 
 
 def emb_scatter_add_bwd(d_ic, d_pos, ic, pos, user, item_ids, cat_ids, pos_ids, user_ids, seq_len, B, L,
-                        reg, with_user, g_item, g_cat, g_pos, g_user, slot_sq_partial):
+                        reg, with_user, g_item, g_cat, g_pos, g_user, slot_sq_partial, pos_table=None):
+    """pos_table given (and pos None): the looked-up position rows were never written out; their L2 term reads
+    the table through the ids (steps whose forward is seq_chain_gather_fwd)."""
     lib = _lib.load()
+    if pos_table is not None:
+        rc = lib.mtam_emb_scatter_add_bwd_postab(
+            _p(d_ic), _p(d_pos), _p(ic), _p(pos), _p(pos_table), _p(user), _pi(item_ids), _pi(cat_ids), _pi(pos_ids),
+            _pi(user_ids), _pi(seq_len), B, L, float(reg), int(with_user), _p(g_item), g_item.shape[0], _p(g_cat),
+            g_cat.shape[0], _p(g_pos), g_pos.shape[0], _p(g_user), g_user.shape[0], _p(slot_sq_partial), _stream())
+        _lib.check(rc, "mtam_emb_scatter_add_bwd_postab")
+        return
     rc = lib.mtam_emb_scatter_add_bwd(_p(d_ic), _p(d_pos), _p(ic), _p(pos), _p(user), _pi(item_ids),
                                       _pi(cat_ids), _pi(pos_ids), _pi(user_ids), _pi(seq_len), B, L,
                                       float(reg), int(with_user), _p(g_item), g_item.shape[0], _p(g_cat),
@@ -345,6 +354,27 @@ def seq_chain_fwd(ic, W4, pos, R, Wkv, bkv, Wx, bx, zr, x, kv, xproj):
     _lib.check(lib.mtam_seq_chain_fwd(_p(ic), _p(W4), _p(pos), R, _p(Wkv), _p(bkv), n_kv, _p(Wx), _p(bx),
                                       Wx.shape[1], _p(zr), _p(x), _p(kv) if n_kv else None, _p(xproj), _stream()),
                "mtam_seq_chain_fwd")
+
+
+def seq_chain_gather_partials(B, L):
+    return _lib.load().mtam_seq_chain_gather_partials(B, L)
+
+
+def seq_chain_gather_fwd(item_table, cat_table, pos_table, user_table, item_ids, cat_ids, pos_ids, user_ids, B, L,
+                         with_user, W4, Wkv, bkv, Wx, bx, ic_out, user_out, l2_partial, zr, x, kv, xproj, clear=()):
+    """The four embedding lookups + dense4emb + K/V projection + GRU input projection in one launch; ic_out None
+    in evaluation.  ``clear``: up to two float tensors zeroed on the side."""
+    lib = _lib.load()
+    n_kv = Wkv.shape[1] if Wkv is not None else 0
+    ca = clear[0] if len(clear) > 0 else None
+    cb = clear[1] if len(clear) > 1 else None
+    rc = lib.mtam_seq_chain_gather_fwd(
+        _p(item_table), item_table.shape[0], _p(cat_table), cat_table.shape[0], _p(pos_table), pos_table.shape[0],
+        _p(user_table), user_table.shape[0], _pi(item_ids), _pi(cat_ids), _pi(pos_ids), _pi(user_ids), B, L,
+        int(with_user), _p(W4), _p(Wkv), _p(bkv), n_kv, _p(Wx), _p(bx), Wx.shape[1], _p(ic_out), _p(user_out),
+        _p(l2_partial), l2_partial.numel(), _p(zr), _p(x), _p(kv) if n_kv else None, _p(xproj),
+        _p(ca), ca.numel() if ca is not None else 0, _p(cb), cb.numel() if cb is not None else 0, _stream())
+    _lib.check(rc, "mtam_seq_chain_gather_fwd")
 
 
 def score32_partials(B, V):

@@ -96,6 +96,8 @@ def test_c4_mtam_10m_items_properties(hip_lib, tmp_path):
     p.eval_kernels(bt, 50, stored=True)
     item_ids = torch.from_numpy(feed["item_list"].astype(np.int64)).cuda().view(-1)
     cat_ids = torch.from_numpy(feed["category_list"].astype(np.int64)).cuda().view(-1)
+    # (the training-mode forward keeps the looked-up [item | category] rows for the backward; evaluation does not)
+    p.forward(bt, training=True, score=False)
     assert torch.equal(bt.ic[:, :128], p.tables["item"][item_ids])
     assert torch.equal(bt.ic[:, 128:], p.tables["category"][cat_ids])
 
@@ -198,6 +200,7 @@ def test_c5_shape_fp32_50m_items_l200(hip_lib, tmp_path):
     p.eval_kernels(bt, 50, stored=True)
     assert torch.equal(bt.topk_idx, streamed_top)
     item_ids = torch.from_numpy(feed["item_list"].astype(np.int64)).cuda().view(-1)
+    p.forward(bt, training=True, score=False)
     assert torch.equal(bt.ic[:, :128], p.tables["item"][item_ids])
     top = bt.topk_idx.long()
     vals = torch.gather(bt.logits, 1, top)

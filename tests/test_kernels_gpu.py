@@ -950,3 +950,45 @@ def test_topk_stream_equals_topk_on_the_stored_matrix(ops, rows, V, slab):
     assert np.array_equal(got.cpu().numpy(), ref)
     with pytest.raises(RuntimeError):                  # a slab must start on a segment boundary
         ops.topk_stream_slab(scratch, slab, rows, 1000, 10, V, k, ws)
+
+
+@pytest.mark.parametrize("B,L,with_user,train", [(128, 50, 1, True), (7, 9, 0, True), (33, 50, 1, False), (1, 2, 1, True)])
+def test_seq_chain_gather_fwd_equals_gather_then_chain(ops, B, L, with_user, train):
+    """mtam_seq_chain_gather_fwd (the four lookups folded into the forward's first GEMM kernel) against
+    mtam_emb_gather_fwd + mtam_seq_chain_fwd: bit-identical zr / x / kv / xproj / user rows and (training) the
+    [item | category] copy; the l2 sum to rounding; side ranges cleared; out-of-range ids clamped the same way."""
+    rng = np.random.default_rng(B * 13 + L)
+    R, n_kv, n_x = B * L, 256, 384
+    V, C, U = 777, 31, 55
+    T = {k: dev(rng.standard_normal((n, D)).astype(np.float32) * 0.3)
+         for k, n in (("item", V), ("cat", C), ("pos", L + 3), ("user", U))}
+    ids = dict(item=rng.integers(0, V, (B, L)), cat=rng.integers(0, C, (B, L)), pos=rng.integers(0, L + 3, (B, L)),
+               user=rng.integers(0, U, B))
+    ids["item"][0, 0] = V + 5                      # clamped like the gather kernel clamps
+    ids = {k: dev(v.astype(np.int32)) for k, v in ids.items()}
+    W4 = dev(rng.standard_normal((2 * D, D)).astype(np.float32) * 0.05)
+    Wkv, bkv = dev(rng.standard_normal((D, n_kv)).astype(np.float32) * 0.05), dev(rng.standard_normal(n_kv).astype(np.float32))
+    Wx, bx = dev(rng.standard_normal((D, n_x)).astype(np.float32) * 0.05), dev(rng.standard_normal(n_x).astype(np.float32))
+    z = lambda *s: torch.full(s, 7.0, device="cuda")
+    # reference: two kernels
+    ic, pos, user = z(R, 2 * D), z(R, D), z(B, D)
+    l2a = torch.zeros(ops.emb_gather_partials(B, L), device="cuda")
+    ops.emb_gather_fwd(T["item"], T["cat"], T["pos"], T["user"], ids["item"], ids["cat"], ids["pos"], ids["user"], B, L,
+                       with_user, ic, pos, user, l2a)
+    ref = [z(R, D), z(R, D), z(R, n_kv), z(R, n_x)]
+    ops.seq_chain_fwd(ic, W4, pos, R, Wkv, bkv, Wx, bx, *ref)
+    # fused
+    got = [z(R, D), z(R, D), z(R, n_kv), z(R, n_x)]
+    ic2, user2 = z(R, 2 * D), z(B, D)
+    l2b = torch.full((ops.seq_chain_gather_partials(B, L) + 37,), 3.0, device="cuda")
+    ca, cb = torch.ones(4 * 1000, device="cuda"), torch.ones(4 * 77, device="cuda")
+    ops.seq_chain_gather_fwd(T["item"], T["cat"], T["pos"], T["user"], ids["item"], ids["cat"], ids["pos"], ids["user"],
+                             B, L, with_user, W4, Wkv, bkv, Wx, bx, ic2 if train else None, user2, l2b, *got,
+                             clear=(ca, cb))
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert torch.equal(user2, user)
+    assert torch.equal(ic2, ic) if train else bool((ic2 == 7.0).all())
+    assert abs(float(l2b.double().sum()) - float(l2a.double().sum())) < 1e-6 * float(l2a.double().sum())
+    assert not bool(l2b[ops.seq_chain_gather_partials(B, L):].any())
+    assert not bool(ca.any()) and not bool(cb.any())
