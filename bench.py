@@ -324,6 +324,31 @@ def main():
         t_scatter = time_kernel([scatter_fn(i) for i in range(n_rot_s)], torch, reps=2 * n_rot_s)
         t_scatter_hot = time_kernel(scatter_fn(0), torch)
         del outs, grads_in
+        # ---- the form the training step actually runs: the lookups folded into the forward's first GEMM kernel
+        # (mtam_seq_chain_gather_fwd: gather + dense4emb + K/V projection + GRU input projection).  MFMA-bound:
+        # 2 R (2D D + D n_kv + D n_x) flops on v_mfma_f32_32x32x2_f32; its HBM side is the fused-variant bound of
+        # SURVEY.md 8(d), (3L+1)(D e + 4) + L D e per sequence of table rows + ids, plus what it must write.
+        t_fused, fused = None, None
+        if args.model == "MTAM" and args.score_dtype == "f32" and getattr(bt, "fused_gather", False):
+            kvw, kvb = (p.seg("kv/w"), p.seg("kv/b")) if p.cfg["keys"] == "x" and p.cfg["attention"] else (None, None)
+
+            def fused_fn(i):
+                f = ids[i % len(ids)]
+                return lambda: ops.seq_chain_gather_fwd(
+                    T["item"], T["category"], T["position"], T["user"], f["item_list"], f["category_list"],
+                    f["position_list"], f["user_id"], B_PER_GPU, L, 1, p.seg("dense4emb/w"), kvw, kvb,
+                    p.seg("gru/wx"), p.seg("gru/bx"), bt.ic, bt.user, bt.l2_partial, bt.zr, bt.x,
+                    bt.kv if kvw is not None else None, bt.xproj)
+            t_fused = time_kernel([fused_fn(i) for i in range(len(ids))], torch, reps=2 * len(ids))
+            n_kv = kvw.shape[1] if kvw is not None else 0
+            flops = 2.0 * R * (2 * D * D + D * n_kv + D * p.seg("gru/wx").shape[1])
+            lookup_bytes = ((3 * L + 1) * (D * 4 + 4) + L * D * 4) * B_PER_GPU
+            fused = {"kernel": "seq_chain_fwd_kernel<true>", "bound": "mfma", "achieved": flops / t_fused / 1e12,
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / t_fused / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                     "traffic": None, "flops_per_launch": flops, "us_per_launch": t_fused * 1e6,
+                     "lookup_bytes_per_launch_fused_bound": lookup_bytes,
+                     "note": "the training step's embedding lookups run inside this kernel; the stand-alone gather "
+                             "kernel of `roofline` is what mtam_emb_gather_fwd callers (PISTRec, bf16 mode) launch"}
         gb = gather_bytes_per_seq(L, D) * B_PER_GPU
         sb = scatter_bytes_per_seq(L, D) * B_PER_GPU
         log("gather %.2f us (one buffer set re-used: %.2f), scatter-add %.2f us (%.2f) per launch"
@@ -359,6 +384,9 @@ def main():
                                      "bytes_per_launch": sb, "us_per_launch": t_scatter * 1e6,
                                      "buffer_sets": n_rot_s, "us_per_launch_cache_hot": t_scatter_hot * 1e6},
         }
+        if fused is not None:
+            result["roofline_fused_forward"] = fused
+            log("fused lookups + projections: %.2f us per launch (%.1f TFLOP/s)" % (t_fused * 1e6, fused["achieved"]))
         if args.score_dtype == "bf16":
             # the two catalog passes of the bf16 scoring (csrc/score16.hip): algorithmic bytes per catalog row =
             # 256 (bf16 row, lse pass) and 256 + 512 (bf16 row read, fp32 gradient row written; backward)
