@@ -265,12 +265,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
   constexpr int LDB_S = TB ? BN + 1 : BN + 4;
   constexpr int A_FLOATS = tile_floats<EA>(), B_FLOATS = tile_floats<BN>();
   constexpr int BM = EA;
-  // Two accumulator chains per 64 x 64 tile (even / odd k) for the gradient epilogues: a dependent
-  // v_mfma_f32_32x32x2_f32 issues every ~84 cycles, an independent one every 64 (tools/gemm_lab.hip), and these
-  // latency-bound launches (one wave per SIMD, a handful of k-tiles) are chains end to end.  NOT for the plain
-  // store epilogues: their results are the k-ORDERED fmaf chain the top-K contract compares bit for bit.
-  constexpr bool CH2 = MW == 1 && (EPI == MTAM_EPI_ATOMIC || EPI == MTAM_EPI_ACCUM || EPI == MTAM_EPI_ACCUM_MASK ||
-                                   EPI == MTAM_EPI_ACCUM2_MASK);
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -338,8 +332,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
       GEMM_STAMP(1);
 #pragma unroll
       for (int q = 0; q < BK / 2; ++q) {
-        if (CH2 && (q & 1)) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc2, 0, 0, 0);
-        else                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q], fb[q], acc, 0, 0, 0);
         if (MW == 2) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa2[q], fb[q], acc2, 0, 0, 0);
       }
       GEMM_STAMP(2);
@@ -403,7 +396,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
   }
 
   }   // sources
-  if (CH2) acc += acc2;
 
   float sq;
   if (EPI != MTAM_EPI_ATOMIC && p.vecC && n0 + wn * 32 + 32 <= p.N) {        // wave-uniform
