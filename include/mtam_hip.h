@@ -205,6 +205,17 @@ int mtam_emb_scatter_add_bwd_postab(const float *d_item_cat, const float *d_pos,
                                     int with_user, float *g_item, int item_rows, float *g_cat, int cat_rows,
                                     float *g_pos, int pos_rows, float *g_user, int user_rows,
                                     float *slot_sq_partial, void *stream);
+/* ... and with the [item | category] gradient rows computed in place (d_item_cat == NULL; d_z [B*L, D] and
+ * W4 = dense4emb's kernel [2D, D] given): every 128-slot chunk of the item (category) table forms its own
+ * 128 x 128 block of  d_z . W4^T  on the matrix cores -- the d[item | category] GEMM and the round trip of its
+ * [B*L, 2D] result through HBM disappear from the step (SURVEY.md 2.1 K11 fused with the dense4emb input gradient). */
+int mtam_emb_scatter_add_bwd_fused(const float *d_item_cat, const float *d_z, const float *W4, const float *d_pos,
+                                   const float *item_cat, const float *pos, const float *pos_table,
+                                   const float *user, const int32_t *item_ids, const int32_t *cat_ids,
+                                   const int32_t *pos_ids, const int32_t *user_ids, const int32_t *seq_len, int B,
+                                   int L, float reg, int with_user, float *g_item, int item_rows, float *g_cat,
+                                   int cat_rows, float *g_pos, int pos_rows, float *g_user, int user_rows,
+                                   float *slot_sq_partial, void *stream);
 
 /* ----------------------------------------------------------- time-aware GRU
  * dynamic_rnn(TimeAwareGRUCell_decay_new) + gather_indexes(seq_len - 2):

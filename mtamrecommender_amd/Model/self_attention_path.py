@@ -9,6 +9,8 @@ cores as batched fp32-MFMA GEMMs (one problem per (sample, head)); the gate / ma
 in ``mtam_ta_selfattn_gate_softmax_*``.  Parameters, loss, clipping and Adam are shared with the
 MTAM path (same flat parameter space).
 """
+import os
+
 import torch
 
 from .. import hip_ops as ops
@@ -130,14 +132,18 @@ class SelfAttentionPath(TimeAwarePath):
         # d_out now holds d loss / d x; dense4emb and the tables
         bt.d_z.copy_(d_out)
         ops.relu_bwd_inplace(bt.d_z, bt.zr, bt.d_z.numel())
-        ops.gemm(bt.d_z, self.seg("dense4emb/w"), bt.d_ic, trans_b=True)
+        fused_scatter = os.environ.get("MTAM_FUSED_SCATTER", "0") == "1"      # see TimeAwarePath.backward
+        if not fused_scatter:
+            ops.gemm(bt.d_z, self.seg("dense4emb/w"), bt.d_ic, trans_b=True)
         ops.gemm_tn_atomic_grouped([dict(A=bt.ic, lda=2 * D, B=bt.d_z, ldb=D, C=gseg("dense4emb/w"), ldc=D,
                                          M=2 * D, N=D, K=R, split_k=sr)])
         slot_part = part[self.nb_dense + self.nb_item:]
-        ops.emb_scatter_add_bwd(bt.d_ic, d_out, bt.ic, bt.pos, bt.user, fd["item_list"], fd["category_list"],
-                                fd["position_list"], fd["user_id"], fd["seq_length"], B, L, self.reg, self.WITH_USER,
-                                self.g_tab["item"], self.g_tab["category"], self.g_tab["position"],
-                                self.g_tab["user"], slot_part)
+        ops.emb_scatter_add_bwd(None if fused_scatter else bt.d_ic, d_out, bt.ic, bt.pos, bt.user, fd["item_list"],
+                                fd["category_list"], fd["position_list"], fd["user_id"], fd["seq_length"], B, L,
+                                self.reg, self.WITH_USER, self.g_tab["item"], self.g_tab["category"],
+                                self.g_tab["position"], self.g_tab["user"], slot_part,
+                                d_z=bt.d_z if fused_scatter else None,
+                                W4=self.seg("dense4emb/w") if fused_scatter else None)
 
 
 class UserL2SelfAttentionPath(SelfAttentionPath):

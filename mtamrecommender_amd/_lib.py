@@ -39,6 +39,8 @@ SIGNATURES = {
                                          P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
     "mtam_emb_scatter_add_bwd_postab": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
                                                 P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
+    "mtam_emb_scatter_add_bwd_fused": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
+                                               P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
     "mtam_seq_chain_gather_partials": (c_int, [c_int, c_int]),
     "mtam_seq_chain_gather_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
                                           P, P, P, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P, P, c_size_t, P,

@@ -139,6 +139,10 @@ struct ScatterArgs {
   // non-NULL: the looked-up position rows were never written out (the gather lives inside the forward's first
   // GEMM kernel, mtam_seq_chain_gather_fwd): the L2 term of a position slot reads its table row through the id
   const float *pos_table;
+  // non-NULL (with d_ic NULL): the [item | category] gradient rows were never written either -- a chunk of the
+  // item (category) table computes its own 128 x 128 block  d_z[chunk rows] . W4[table half]^T  on the matrix cores
+  // (dense4emb's input gradient, Embedding/Behavior_embedding_time_aware_attention.py:95-101 under tf.gradients)
+  const float *d_z, *W4;
 };
 
 // Scatter-add with a per-workgroup duplicate pre-reduction.
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
   float *g;
   int rows, stride;
   if (table == 0)      { d_base = p.d_ic;     e_base = p.ic;     ids = p.item_ids; g = p.g_item; rows = p.item_rows; stride = 2 * D; }
-  else if (table == 1) { d_base = p.d_ic + D; e_base = p.ic + D; ids = p.cat_ids;  g = p.g_cat;  rows = p.cat_rows;  stride = 2 * D; }
+  else if (table == 1) { d_base = p.d_ic ? p.d_ic + D : nullptr; e_base = p.ic + D; ids = p.cat_ids;  g = p.g_cat;  rows = p.cat_rows;  stride = 2 * D; }
   else if (table == 2) { d_base = p.d_pos;    e_base = p.pos;    ids = p.pos_ids;  g = p.g_pos;  rows = p.pos_rows;  stride = D; }
   else                 { d_base = nullptr;    e_base = p.user;   ids = p.user_ids; g = p.g_user; rows = p.user_rows; stride = D; }
 
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
     sl[k] = p.seq_len[min(bb, p.B - 1)];
   }
   float v[SPH][4], dv[SPH][4];
+  const bool fused_dic = table <= 1 && p.d_z != nullptr;                  // block-uniform
   const bool pos_from_table = table == 2 && p.pos_table != nullptr;      // block-uniform
 #pragma unroll
   for (int k = 0; k < SPH; ++k) {
@@ -272,7 +277,39 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[k][q] = e[32 * q];
   }
-  if (d_base) {                                   // block-uniform
+  if (fused_dic) {
+    // ---- this chunk's block of d[item | category] = d_z . W4^T, 128 slots x 128 columns, on 16 waves (one 32 x 32
+    // tile each, K = 128 in two halves of 32 k-steps), through `stage` into the half waves' row layout
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int tm = wave_in_block >> 2, tn = wave_in_block & 3, r = lane & 31, h = lane >> 5;
+    const float *arow = p.d_z + (size_t)min(q0 + 32 * tm + r, R - 1) * D + 64 * h;
+    const float *brow = p.W4 + (size_t)(table * D + 32 * tn + r) * D + 64 * h;
+    f32x16 acc = {0.f};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float a[32], b[32];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 x = *reinterpret_cast<const float4 *>(arow + 32 * half + 4 * i);
+        const float4 y = *reinterpret_cast<const float4 *>(brow + 32 * half + 4 * i);
+        a[4 * i] = x.x; a[4 * i + 1] = x.y; a[4 * i + 2] = x.z; a[4 * i + 3] = x.w;
+        b[4 * i] = y.x; b[4 * i + 1] = y.y; b[4 * i + 2] = y.z; b[4 * i + 3] = y.w;
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < 32; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_], b[s_], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) stage[32 * tm + (q & 3) + 8 * (q >> 2) + 4 * h][32 * tn + r] = acc[q];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SPH; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dv[k][q] = stage[hw + NHW * k][li + 32 * q];
+    // (the barrier below, after the row loads, separates these reads from the followers' later writes to `stage`)
+  }
+  if (fused_dic) {
+    // (dv came off the matrix cores just above, while the row loads issued before it were in flight)
+  } else if (d_base) {                            // block-uniform
 #pragma unroll
     for (int k = 0; k < SPH; ++k) {
       const float *d = d_base + (size_t)max(cand[k], 0) * stride + li;
@@ -463,10 +500,25 @@ extern "C" int mtam_emb_scatter_add_bwd_postab(const float *d_item_cat, const fl
                                                float *g_item, int item_rows, float *g_cat, int cat_rows, float *g_pos,
                                                int pos_rows, float *g_user, int user_rows, float *slot_sq_partial,
                                                void *stream) {
+  return mtam_emb_scatter_add_bwd_fused(d_item_cat, nullptr, nullptr, d_pos, item_cat, pos, pos_table, user, item_ids,
+                                        cat_ids, pos_ids, user_ids, seq_len, B, L, reg, with_user, g_item, item_rows,
+                                        g_cat, cat_rows, g_pos, pos_rows, g_user, user_rows, slot_sq_partial, stream);
+}
+
+extern "C" int mtam_emb_scatter_add_bwd_fused(const float *d_item_cat, const float *d_z, const float *W4,
+                                              const float *d_pos, const float *item_cat, const float *pos,
+                                              const float *pos_table, const float *user, const int32_t *item_ids,
+                                              const int32_t *cat_ids, const int32_t *pos_ids,
+                                              const int32_t *user_ids, const int32_t *seq_len, int B, int L, float reg,
+                                              int with_user, float *g_item, int item_rows, float *g_cat, int cat_rows,
+                                              float *g_pos, int pos_rows, float *g_user, int user_rows,
+                                              float *slot_sq_partial, void *stream) {
   MTAM_CHECK_ARG(B > 0 && L > 0, "emb_scatter: B and L must be positive");
   MTAM_CHECK_ARG((long)B * L * 3 + B < 0x3fffffffL, "emb_scatter: batch too large");
-  MTAM_CHECK_ARG(d_item_cat && d_pos && item_cat && (pos || pos_table) && user,
+  MTAM_CHECK_ARG((d_item_cat || (d_z && W4)) && d_pos && item_cat && (pos || pos_table) && user,
                  "emb_scatter: null gradient or gathered rows");
+  MTAM_CHECK_ARG(d_item_cat || (mtam_aligned16(d_z) && mtam_aligned16(W4)),
+                 "emb_scatter: d_z and W4 must be 16-byte aligned");
   MTAM_CHECK_ARG(item_ids && cat_ids && pos_ids && user_ids && seq_len, "emb_scatter: null ids");
   MTAM_CHECK_ARG(g_item && g_cat && g_pos && (g_user || !with_user) && slot_sq_partial, "emb_scatter: null output");
   MTAM_CHECK_ARG(item_rows > 0 && cat_rows > 0 && pos_rows > 0 && user_rows > 0, "emb_scatter: empty table");
@@ -474,7 +526,8 @@ extern "C" int mtam_emb_scatter_add_bwd_postab(const float *d_item_cat, const fl
                 B, L, with_user, reg, g_item, g_cat, g_pos, g_user,
                 item_rows, cat_rows, pos_rows, user_rows, slot_sq_partial,
                 scatter_rm_chunks(B, L), scatter_tr_chunks(B, L), with_user ? scatter_user_chunks(B) : 0,
-                mtam_emb_scatter_partials(B, L), pos ? nullptr : pos_table};
+                mtam_emb_scatter_partials(B, L), pos ? nullptr : pos_table, d_item_cat ? nullptr : d_z,
+                d_item_cat ? nullptr : W4};
   hipLaunchKernelGGL(emb_scatter_kernel, dim3(2 * a.n_rm + a.n_tr + a.n_user + 1), dim3(SCATTER_THREADS), 0,
                      static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("emb_scatter");

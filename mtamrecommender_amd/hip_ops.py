@@ -121,10 +121,20 @@ def emb_scatter_partials(B, L):
 
 
 def emb_scatter_add_bwd(d_ic, d_pos, ic, pos, user, item_ids, cat_ids, pos_ids, user_ids, seq_len, B, L,
-                        reg, with_user, g_item, g_cat, g_pos, g_user, slot_sq_partial, pos_table=None):
+                        reg, with_user, g_item, g_cat, g_pos, g_user, slot_sq_partial, pos_table=None, d_z=None,
+                        W4=None):
     """pos_table given (and pos None): the looked-up position rows were never written out; their L2 term reads
-    the table through the ids (steps whose forward is seq_chain_gather_fwd)."""
+    the table through the ids (steps whose forward is seq_chain_gather_fwd).  d_z and W4 given (and d_ic None): the
+    [item | category] gradient rows are computed inside the kernel, d_z . W4^T per 128-slot chunk."""
     lib = _lib.load()
+    if d_z is not None:
+        rc = lib.mtam_emb_scatter_add_bwd_fused(
+            _p(d_ic), _p(d_z), _p(W4), _p(d_pos), _p(ic), _p(pos), _p(pos_table), _p(user), _pi(item_ids),
+            _pi(cat_ids), _pi(pos_ids), _pi(user_ids), _pi(seq_len), B, L, float(reg), int(with_user), _p(g_item),
+            g_item.shape[0], _p(g_cat), g_cat.shape[0], _p(g_pos), g_pos.shape[0], _p(g_user), g_user.shape[0],
+            _p(slot_sq_partial), _stream())
+        _lib.check(rc, "mtam_emb_scatter_add_bwd_fused")
+        return
     if pos_table is not None:
         rc = lib.mtam_emb_scatter_add_bwd_postab(
             _p(d_ic), _p(d_pos), _p(ic), _p(pos), _p(pos_table), _p(user), _pi(item_ids), _pi(cat_ids), _pi(pos_ids),
