@@ -224,7 +224,10 @@ class TimeAwarePath(object):
         # data-parallel exchange can cut it into 1, 2, 4 or 8 equal row ranges (data_parallel.ShardedItemExchange);
         # the pad rows are zero, never looked up, scored or updated (every kernel gets the true counts)
         self.item_rows_pad = (self.item_rows + 7) // 8 * 8
-        self.n_alloc = o + (self.item_rows_pad - self.item_rows) * D
+        # ... plus one more row at the very end: under the flat data-parallel exchange the first floats of it in the
+        # GRADIENT buffer carry the rank's loss terms through the same all-reduce as the gradients (loss_tail)
+        self.n_items_end = o + (self.item_rows_pad - self.item_rows) * D
+        self.n_alloc = self.n_items_end + D
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_p, self.flat_g, self.flat_m, self.flat_v = (z(self.n_alloc), z(self.n_alloc), z(self.n_alloc),
                                                               z(self.n_alloc))
@@ -276,6 +279,8 @@ class TimeAwarePath(object):
         # (Independent branches of the step were tried on side streams -- K/V projection next to the GRU,
         # weight-gradient GEMMs next to the serial chain: 388 us/step vs 366 us in one stream at B=128; the
         # cross-queue graph edges cost more than the overlap won, so the step is single-stream.)
+        self.loss_tail = self.flat_g[self.n_items_end:self.n_items_end + 4]
+        self.loss_in_tail = False       # data_parallel.attach(): the reported loss is the all-reduced tail
         self.allreduce_fn = None        # set by data_parallel.attach()
         self.sharded = None             # data_parallel.ShardedItemExchange: replaces allreduce_fn + clip_and_apply
         self.world_size = 1             # the loss is a mean over world_size * B samples ...
@@ -293,6 +298,8 @@ class TimeAwarePath(object):
     def batch(self, B):
         if B not in self._batches:
             self._batches[B] = (self.BATCH_CLASS or _Batch)(self, B)
+            if self.loss_in_tail:
+                self._batches[B].loss = self.loss_tail[:3]
         return self._batches[B]
 
     def fill_host(self, bt, feed, lr=None):
@@ -585,7 +592,7 @@ class TimeAwarePath(object):
         gb = self.gb(bt)
         ops.sqnorm_clip_scale(self.flat_g, n_g, part, 0, n, self.clip, self.scale, bt.feed["lr"],
                               self.adam_state, self.ticket, bt.l2_partial, bt.l2_partial.numel(), bt.ce, bt.B,
-                              self.reg, 1.0 / gb, bt.loss)
+                              self.reg, 1.0 / gb, None if self.loss_in_tail else bt.loss)
         if self.optimizer == "adam" and self.item16 is not None:
             # the bf16 scoring copy of the item table is refreshed by the same launch
             ops.adam_bf16copy(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,

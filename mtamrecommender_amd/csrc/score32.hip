@@ -581,8 +581,8 @@ __global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
 // next slab, score it, turn the scores into the three G images) while waves 4..7, their SIMD partners, CONSUME
 // (dE and d_pred of the current slab): vector work of one role runs beside matrix work of the other.
 //   phase a   P: split E(s + 1) -> e[next]                 C: dE(s)            <- g
-//   phase b   P: scores(s + 1)  <- e[next]                  C: d_pred(s), blocks 0, 1  <- gt[cur], e[cur]
-//   phase c   P: G(s + 1) -> g, gt[next]                    C: d_pred(s), blocks 2, 3  <- gt[cur], e[cur]
+//   phase b   P: scores(s + 1)  <- e[next]                  C: d_pred(s), block 0      <- gt[cur], e[cur]
+//   phase c   P: G(s + 1) -> g, gt[next]                    C: d_pred(s), blocks 1..3  <- gt[cur], e[cur]
 // E images and G^T images are double-buffered, G single (140 KB of LDS); three barriers per slab, as before.
 constexpr int T_PITCH = 36;             // per consumer wave: a 32 x 32 fp32 tile on its way out, rows 36 floats apart
 constexpr int PC_SCRATCH = 4 * 32 * T_PITCH * 4;
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(512) void bwd_pc_kernel(BwdArgs p) {
   for (int i = 0; i < 4; ++i) dp[i] = f32x16{0.f};
   float sq = 0.f;
   const unsigned char *const g_rd = g_img + r * G_PITCH + 16 * h;
-  auto dpred_blocks = [&](const unsigned char *e_img, const unsigned char *gt_img, int m0) {
+  auto dpred_blocks = [&](const unsigned char *e_img, const unsigned char *gt_img, const int m0, const int m1) {
     const unsigned char *const gt_rd = gt_img + r * GT_PITCH + 16 * h;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -706,7 +706,8 @@ __global__ __launch_bounds__(512) void bwd_pc_kernel(BwdArgs p) {
         bfrag.t[t] = __builtin_bit_cast(bf16x8, pk);
       }
 #pragma unroll
-      for (int mblk = m0; mblk < m0 + 2; ++mblk) {
+      for (int mblk = 0; mblk < 4; ++mblk) {
+        if (mblk < m0 || mblk >= m1) continue;
         Tri a;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -778,9 +779,11 @@ __global__ __launch_bounds__(512) void bwd_pc_kernel(BwdArgs p) {
     }
     __syncthreads();
     // phases b, c: d_pred[b][d] += sum_v G[v][b] E[v][d]   (this wave: columns d = 32 w .., two 32-row blocks each)
-    dpred_blocks(e_cur, gt_cur, 0);
+    // (one block beside the producers' 48 score MFMAs, three beside their exp + split: 60 / 36 MFMAs per SIMD in
+    // phases b / c instead of 72 / 24)
+    dpred_blocks(e_cur, gt_cur, 0, 1);
     __syncthreads();
-    dpred_blocks(e_cur, gt_cur, 2);
+    dpred_blocks(e_cur, gt_cur, 1, 4);
     __syncthreads();
   }
 #pragma unroll

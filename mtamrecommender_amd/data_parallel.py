@@ -57,8 +57,17 @@ def attach(path, world_size, group=None, force=False, shard_items=None):
         path.sharded = ShardedItemExchange(path, max(world_size, 1), rank, group)
         return
 
+    # The reported loss is a sum over ranks too (reg * l2 is a plain sum, the cross entropy a mean over the GLOBAL
+    # batch): each rank's terms ride in the tail of the gradient buffer through the same all-reduce, so every rank
+    # reports the loss of the whole batch without a collective of its own.
+    from . import hip_ops as ops
+    path.loss_in_tail = True
+    for bt in path._batches.values():
+        bt.loss = path.loss_tail[:3]
+
     def exchange(p, bt):
-        allreduce_gradients([p.flat_g[:p.n_total]], group)
+        ops.loss_reduce(bt.l2_partial, bt.l2_partial.numel(), bt.ce, bt.B, p.reg, 1.0 / p.gb(bt), p.loss_tail)
+        allreduce_gradients([p.flat_g[:p.n_items_end + 4]], group)
 
     path.allreduce_fn = exchange
 

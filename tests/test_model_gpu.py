@@ -195,8 +195,9 @@ def test_data_parallel_code_path_single_rank(hip_lib, tmp_path, dp_mode):
         data_parallel.broadcast_parameters(model_b.path)
         for step in range(4):
             la, _ = model_a.train(model_a.sess, records, 1e-3)
-            lb, _ = model_b.train(model_b.sess, records, 1e-3)
+            lb, _ = model_b.train(model_b.sess, records, 1e-3)   # (its loss travelled through the all-reduce's tail)
             assert abs(la - lb) <= 1e-6 * abs(la), step
+        assert model_b.path.loss_in_tail and model_b.path.batch(32).loss.data_ptr() == model_b.path.loss_tail.data_ptr()
         assert model_b._dp_mode == dp_mode                  # "fused" did not fall back
         assert (("train_dp", 32, None) in model_b._graphs) == (dp_mode == "fused")
         va, vb = model_a.get_variables(), model_b.get_variables()
