@@ -47,22 +47,38 @@ __global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float *__rest
   }
 }
 
+// A workgroup takes LN_BWD_ROWS rows (a wave: every fourth of them, all its loads issued before the first use) and
+// adds its sums for d(beta), d(gamma) ONCE: with 4 rows per workgroup, 3,200 workgroups piled 256 float atomics each
+// on the same 256 addresses at 12,800 rows (80 us; same-address atomics serialise at the memory side).
+constexpr int LN_BWD_ROWS = 32;
 __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float *__restrict__ dy, const float *gamma,
                                                              const float *__restrict__ save, int rows,
                                                              float *__restrict__ dx, float *d_bg) {
   __shared__ float sb[4][D], sg[4][D];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = blockIdx.x * 4 + wv;
+  constexpr int IT = LN_BWD_ROWS / 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * LN_BWD_ROWS + wv;
+  const float gm0 = gamma[lane], gm1 = gamma[64 + lane];
+  float y0[IT], y1[IT], h0[IT], h1[IT], rs[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const size_t row = min(row0 + 4 * i, rows - 1);          // clamped: rows past the end are masked below
+    y0[i] = dy[row * D + lane]; y1[i] = dy[row * D + 64 + lane];
+    h0[i] = save[row * (D + 1) + lane]; h1[i] = save[row * (D + 1) + 64 + lane];
+    rs[i] = save[row * (D + 1) + D];
+  }
   float b0 = 0.f, b1 = 0.f, g0 = 0.f, g1 = 0.f;
-  if (row < rows) {
-    const float y0 = dy[(size_t)row * D + lane], y1 = dy[(size_t)row * D + 64 + lane];
-    const float h0 = save[(size_t)row * (D + 1) + lane], h1 = save[(size_t)row * (D + 1) + 64 + lane];
-    const float rstd = save[(size_t)row * (D + 1) + D];
-    const float a0 = y0 * gamma[lane], a1 = y1 * gamma[64 + lane];
-    const float m1 = wave_sum(a0 + a1) / (float)D;
-    const float m2 = wave_sum(a0 * h0 + a1 * h1) / (float)D;
-    dx[(size_t)row * D + lane] = rstd * (a0 - m1 - h0 * m2);
-    dx[(size_t)row * D + 64 + lane] = rstd * (a1 - m1 - h1 * m2);
-    b0 = y0; b1 = y1; g0 = y0 * h0; g1 = y1 * h1;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int row = row0 + 4 * i;
+    if (row < rows) {
+      const float a0 = y0[i] * gm0, a1 = y1[i] * gm1;
+      const float m1 = wave_sum(a0 + a1) / (float)D;
+      const float m2 = wave_sum(a0 * h0[i] + a1 * h1[i]) / (float)D;
+      dx[(size_t)row * D + lane] = rs[i] * (a0 - m1 - h0[i] * m2);
+      dx[(size_t)row * D + 64 + lane] = rs[i] * (a1 - m1 - h1[i] * m2);
+      b0 += y0[i]; b1 += y1[i]; g0 = fmaf(y0[i], h0[i], g0); g1 = fmaf(y1[i], h1[i], g1);
+    }
   }
   sb[wv][lane] = b0; sb[wv][64 + lane] = b1; sg[wv][lane] = g0; sg[wv][64 + lane] = g1;
   __syncthreads();
@@ -462,7 +478,7 @@ extern "C" int mtam_layer_norm_fwd(const float *x, const float *resid, const flo
 extern "C" int mtam_layer_norm_bwd(const float *d_y, const float *gamma, const float *save, int rows,
                                    float *d_x, float *d_bg, void *stream) {
   MTAM_CHECK_ARG(d_y && gamma && save && d_x && d_bg && rows > 0, "layer_norm_bwd: bad arguments");
-  hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0,
+  hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3((rows + LN_BWD_ROWS - 1) / LN_BWD_ROWS), dim3(256), 0,
                      static_cast<hipStream_t>(stream), d_y, gamma, save, rows, d_x, d_bg);
   MTAM_CHECK_LAUNCH("layer_norm_bwd");
   return MTAM_OK;

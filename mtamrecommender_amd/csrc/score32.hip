@@ -17,6 +17,44 @@
 #include "common.h"
 #include <stdlib.h>
 
+// In-kernel stamps for tools/score_lab.hip (a diagnostic build, -DMTAM_SCORE_STAMPS): timer ticks per segment of a
+// slab iteration, summed per wave of the middle workgroup and written to a buffer of their own.  The product build
+// has none.
+#ifdef MTAM_SCORE_STAMPS
+__device__ unsigned long long g_score_stamps[2][12][8];     // [kernel][wave][segment]; segment 7 = s_memrealtime ticks
+__device__ unsigned long long g_score_wg[2][4096][3];       // [kernel][workgroup]: start, end (s_memrealtime), HW_ID | XCC_ID << 32
+#define SC_STAMP_DECL unsigned long long st_last_ = 0, st_real_ = 0, st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SC_STAMP_START                                                                 \
+  st_real_ = __builtin_amdgcn_s_memrealtime();                                         \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last_)::"memory");
+#define SC_STAMP(i)                                                                    \
+  {                                                                                    \
+    unsigned long long t_;                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    st_acc_[i] += t_ - st_last_;                                                       \
+    st_last_ = t_;                                                                     \
+  }
+#define SC_WAIT_VM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define SC_STAMP_DUMP(k)                                                               \
+  st_acc_[7] = __builtin_amdgcn_s_memrealtime() - st_real_;                            \
+  if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {                      \
+    g_score_wg[k][blockIdx.x][0] = st_real_;                                           \
+    g_score_wg[k][blockIdx.x][1] = st_real_ + st_acc_[7];                              \
+    g_score_wg[k][blockIdx.x][2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |      \
+                                   ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); \
+  }                                                                                    \
+  if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && (threadIdx.x & 63) == 0)       \
+    for (int i_ = 0; i_ < 8; ++i_) g_score_stamps[k][threadIdx.x >> 6][i_] = st_acc_[i_];
+#else
+#define SC_STAMP_DECL
+#define SC_STAMP_START
+#define SC_STAMP(i)
+#define SC_WAIT_VM
+#define SC_STAMP_DUMP(k)
+#endif
+
 namespace {
 
 constexpr int D = MTAM_D;
@@ -163,9 +201,6 @@ struct BwdArgs {
   int V, Bt, slabs_per_wg;
   float scale;
   float *d_pred, *dE, *sq_partial;
-  int lab;      // developer switches (MTAM_SCORE32_LAB, tools/score32_time.py): parts of x3::bwd_pc_kernel cut out to
-                // time the rest -- 1: no dE stores, 2: no G[v][b] element writes, 4: no E^T gathers for d_pred,
-                // 8: no exp.  0 in every product run.
 };
 
 template <bool RMW>
@@ -303,12 +338,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int E_PITCH = 272;             // bytes per staged row image: 128 bf16 + 16
-constexpr int E_IMG = SLAB * E_PITCH;    // one of the three images of a 32-row slab
-constexpr int G_PITCH = 272;             // G[v][b]: 128 b x 2 B + 16
-constexpr int G_IMG = SLAB * G_PITCH;
-constexpr int GT_PITCH = 80;             // G^T[b][v]: 32 v x 2 B + 16
-constexpr int GT_IMG = BT * GT_PITCH;
+// Which slabs a workgroup takes.  BLOCKED (slabs_per_wg > 0): a contiguous range.  CYCLIC (slabs_per_wg <= 0):
+// slabs c, c + G, c + 2 G, ..: at any moment the grid reads ONE contiguous window of G x 16 KB instead of G streams a
+// fixed multiple of 128 KB apart, which advance in step and so lean on the same memory channels together.
+struct SlabWalk {
+  int first, step, n;
+};
+__device__ __forceinline__ SlabWalk slab_walk(int c, int G, int slabs_per_wg, int nslab) {
+  if (slabs_per_wg > 0) {
+    const int s0 = min(c * slabs_per_wg, nslab);
+    return {s0, 1, min(nslab, s0 + slabs_per_wg) - s0};
+  }
+  return {c, G, c < nslab ? (nslab - c + G - 1) / G : 0};
+}
+
 
 __device__ __forceinline__ void split3(float x, __bf16 &a, __bf16 &b, __bf16 &c) {
   a = (__bf16)x;
@@ -339,31 +382,6 @@ __device__ __forceinline__ f32x16 mfma6(const Tri &a, const Tri &b, f32x16 acc) 
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[0], acc, 0, 0, 0);
   return acc;
 }
-// staged fp32 slab (4 x 16 B per thread) -> three bf16 images in LDS
-__device__ __forceinline__ void stage_store_split(const Stage &st, unsigned char *e_img, int tid) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = i * 256 + tid, row = c >> 5, col = (c & 31) * 4;
-    const float x[4] = {st.v[i].x, st.v[i].y, st.v[i].z, st.v[i].w};
-    bf16x4 q[3];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __bf16 a, b, cc;
-      split3(x[j], a, b, cc);
-      q[0][j] = a; q[1][j] = b; q[2][j] = cc;
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4 *>(e_img + t * E_IMG + row * E_PITCH + col * 2) = q[t];
-  }
-}
-// A fragment (rows v = r, k = d = 16 s + 8 h ..) of the three images
-__device__ __forceinline__ Tri e_frag(const unsigned char *e_img, int s, int r, int h) {
-  Tri o;
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-    o.t[t] = *reinterpret_cast<const bf16x8 *>(e_img + t * E_IMG + r * E_PITCH + 32 * s + 16 * h);
-  return o;
-}
 // the wave's 32 batch rows as an operand (row b, k = d = 16 s + 8 h + j), split
 __device__ __forceinline__ void load_pred_rows(Tri (&p1)[8], const float *__restrict__ row, int h) {
 #pragma unroll
@@ -374,41 +392,93 @@ __device__ __forceinline__ void load_pred_rows(Tri (&p1)[8], const float *__rest
     p1[s] = split8(x);
   }
 }
-__device__ __forceinline__ f32x16 slab_scores(const unsigned char *e_img, const Tri (&p1)[8], int r, int h) {
-  f32x16 acc = {0.f};
+// ---- LDS images of the split operands ([rows][128 x bf16], 256-byte rows; G^T: [128 b][32 v], 64-byte rows): one
+// image serves row reads (ds_read_b128) and transposed reads (ds_read_b64_tr_b16) through a chunk swizzle
+constexpr int E2_IMG = SLAB * 256;       // one of the three images of a 32-row slab
+constexpr int GT2_IMG = BT * 64;         // G^T[b][v]: 128 rows of 32 v
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int e_off(int row, int ch) {      // 16-byte chunk ch (0..15) of image row `row`
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+__device__ __forceinline__ int gt_off(int b, int ch) {       // 16-byte chunk ch (0..3) of G^T row b
+  return 64 * b + 16 * (ch ^ ((b >> 2) & 3));
+}
+__device__ __forceinline__ bf16x8 lds_tr8(const unsigned char *lo, const unsigned char *hi) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(lo));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(hi));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// staged fp32 slab (4 x 16 B per thread of a 256-thread role) -> three swizzled bf16 images
+__device__ __forceinline__ void stage_store_split_tr(const Stage &st, unsigned char *e_img, int tid) {
 #pragma unroll
-  for (int s = 0; s < 8; ++s) acc = mfma6(e_frag(e_img, s, r, h), p1[s], acc);
-  return acc;
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid, row = c >> 5, piece = c & 31;
+    const float x[4] = {st.v[i].x, st.v[i].y, st.v[i].z, st.v[i].w};
+    bf16x4 q[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __bf16 a, b, cc;
+      split3(x[j], a, b, cc);
+      q[0][j] = a; q[1][j] = b; q[2][j] = cc;
+    }
+    unsigned char *const dst = e_img + e_off(row, piece >> 1) + 8 * (piece & 1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4 *>(dst + t * E2_IMG) = q[t];
+  }
 }
 
+// Forward: the log-sum-exp of the scores, one role.  4 waves take a slab in turn through split, barrier, 48 MFMAs,
+// (max, sum-exp), barrier: 5,056 cycles a slab per wave with 1,536 of MFMA issue, 2-3 workgroups per CU; 2.27 ms at
+// 10 M rows.  Two forms with the work cut by role (S waves scoring slab i with the fold of slab i - 1 between their
+// MFMAs, one or two groups of loader waves splitting slab i + 1) measured the same 2.3-2.4 ms
+// (profiles/r02_score32_lse_two_role_retired.hip.txt): the matrix pipe is 56-67 % busy in all of them and the clock
+// sits at 1.7 GHz.
 __global__ __launch_bounds__(256) void lse_kernel(const float *__restrict__ E, const float *__restrict__ P, int V,
                                                   int B, int slabs_per_wg, float *__restrict__ partial) {
-  __shared__ __attribute__((aligned(16))) unsigned char e_img[3 * E_IMG];
+  __shared__ __attribute__((aligned(16))) unsigned char e_img[3 * E2_IMG];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
   const int chunks = gridDim.x, c = blockIdx.x;
   const long b = (long)blockIdx.y * BT + 32 * w + r;
   const int nslab = (V + SLAB - 1) / SLAB;
-  const int slab0 = min(c * slabs_per_wg, nslab), slab1 = min(nslab, slab0 + slabs_per_wg);
+  const SlabWalk wk = slab_walk(c, chunks, slabs_per_wg, nslab);
   Tri p1[8];
   load_pred_rows(p1, P + min(b, (long)B - 1) * D, h);
+  const int swz_r = ((r & 3) << 2) | ((r >> 2) & 3);
   float m = -INFINITY, ssum = 0.f;
   Stage st;
-  if (slab0 < slab1) stage_load(st, E, slab0 * SLAB, V, tid);
-  for (int sl = slab0; sl < slab1; ++sl) {
-    stage_store_split(st, e_img, tid);
+  SC_STAMP_DECL
+  if (wk.n > 0) stage_load(st, E, wk.first * SLAB, V, tid);
+  SC_STAMP_START
+  for (int i = 0; i < wk.n; ++i) {
+    const int sl = wk.first + i * wk.step;
+    SC_WAIT_VM
+    SC_STAMP(0)      // the slab's rows landed
+    stage_store_split_tr(st, e_img, tid);
+    SC_STAMP(1)      // split + LDS writes
     __syncthreads();
-    if (sl + 1 < slab1) stage_load(st, E, (sl + 1) * SLAB, V, tid);
-    f32x16 acc = slab_scores(e_img, p1, r, h);
+    SC_STAMP(2)      // barrier 1
+    if (i + 1 < wk.n) stage_load(st, E, (sl + wk.step) * SLAB, V, tid);
+    f32x16 acc = {0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      Tri a;
+      const int o = 256 * r + 16 * ((2 * s + h) ^ swz_r);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) a.t[t] = *reinterpret_cast<const bf16x8 *>(e_img + t * E2_IMG + o);
+      acc = mfma6(a, p1[s], acc);
+    }
+    SC_STAMP(3)      // next loads issued, 48 MFMAs (+ fragment reads)
     const int vbase = sl * SLAB + 4 * h;
-    const int vlim = (sl * SLAB + SLAB <= V) ? 0x7fffffff : V;
+    if (sl * SLAB + SLAB > V) {              // the catalog's last slab (wave-uniform)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = (vbase + (q & 3) + 8 * (q >> 2) < V) ? acc[q] : -INFINITY;
+    }
     float mx = m;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int v = vbase + (q & 3) + 8 * (q >> 2);
-      const float x = (v < vlim) ? acc[q] : -INFINITY;
-      acc[q] = x;
-      mx = fmaxf(mx, x);
-    }
+    for (int q = 0; q < 16; ++q) mx = fmaxf(mx, acc[q]);
     const float ref = (mx == -INFINITY) ? 0.f : mx;
     const float nref = -ref * L2E;
     float add = 0.f;
@@ -416,8 +486,11 @@ __global__ __launch_bounds__(256) void lse_kernel(const float *__restrict__ E, c
     for (int q = 0; q < 16; ++q) add += fast_exp2(fmaf(acc[q], L2E, nref));
     ssum = ssum * fast_exp2(fmaf(m, L2E, nref)) + add;
     m = mx;
+    SC_STAMP(4)      // max, exp, sum
     __syncthreads();
+    SC_STAMP(5)      // barrier 2
   }
+  SC_STAMP_DUMP(0)
   const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(ssum, 32, 64);
   const float mm = fmaxf(m, m2), ref = (mm == -INFINITY) ? 0.f : mm;
   const float ss = ssum * fast_exp2((m - ref) * L2E) + s2 * fast_exp2((m2 - ref) * L2E);
@@ -427,252 +500,180 @@ __global__ __launch_bounds__(256) void lse_kernel(const float *__restrict__ E, c
   }
 }
 
-constexpr int BWD_LDS = 3 * E_IMG + 3 * G_IMG + 3 * GT_IMG;      // 82,944 B
+// ---- backward: G, d_pred and dE of a slab with the transposes done by the LDS read (ds_read_b64_tr_b16).
+// Two earlier forms are kept, not built, in profiles/r02_score32_bwd_variants_retired.hip.txt: producer / consumer
+// waves with G[v][b] and G^T[b][v] images, two-byte LDS accesses and three barriers a slab (9,400 cycles a slab against
+// 4,608 of MFMA issue per SIMD, tools/score_lab.hip), and a two-role form of what follows (7,240).
+//   * the score tile S[v][b] of a wave has its rows v in the 16 registers and its column b on the lane.
+//     dE[v][d] = sum_b G[v][b] pred[b][d] sums over the COLUMN index: the lane writes its registers as 8-byte pieces of
+//     a G^T[b][v] image (64-byte rows) and the dE role reads that image back transposed, as its A operand;
+//   * d_pred[b][d] += sum_v G[v][b] E[v][d] takes A = row reads of the same G^T image and B = transposed reads of
+//     the row-major E images;
+//   * so there is no G[v][b] image, no two-byte LDS access, and ONE barrier per slab.
+// Images ([rows][128 x bf16], 256-byte rows; G^T: 64-byte rows) serve row reads (ds_read_b128) and transposed reads
+// alike through the chunk swizzles of e_off() / gt_off(); both kinds of read and the writes are bank-conflict free.
+constexpr int T_PITCH = 36;             // per dE wave: a 32 x 32 fp32 tile on its way out, rows 36 floats apart
+constexpr int OUT_SCRATCH = 4 * 32 * T_PITCH * 4;
+// Three roles of 48 MFMAs a slab each, three waves per SIMD (768 threads, <= 168 registers each):
+//     waves 0..3  (S)  scores(i) <- e[i % 3];  G(i) -> gt[i & 1];  split E(i + 1) -> e[(i + 1) % 3];  fetch E(i + 2)
+//     waves 4..7  (D)  d_pred(i - 1) <- gt[(i - 1) & 1], e[(i - 1) % 3]
+//     waves 8..11 (T)  dE(i - 1) <- gt[(i - 1) & 1]
+// E images triple-buffered, G^T double (138 KB of LDS).  6,330 cycles a slab, the matrix pipe 76 % busy
+// (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / 4, profiles/r02_score32_sq_counters.md); the staging placed with
+// D, or shared by S and D, gives the same slab time.  The clock falls as the pipe fills: 1.83 GHz in the
+// three-barrier form, 1.59 GHz here (s_memtime against s_memrealtime), and v_mfma_f32_32x32x16_bf16 alone on random
+// operands holds 1.9 GHz = 1.87 PFLOP/s (tools/mfma_lab.hip), not the 2.5 of constant operands.
+constexpr int TR3_LDS = 3 * 3 * E2_IMG + 2 * 3 * GT2_IMG + OUT_SCRATCH;      // 141,312 B
 
 template <bool RMW>
-__global__ __launch_bounds__(256) void bwd_kernel(BwdArgs p) {
+__global__ __launch_bounds__(768) void bwd_tr3_kernel(BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char *const e_img = lds, *const g_img = lds + 3 * E_IMG, *const gt_img = g_img + 3 * G_IMG;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int V = p.V;
-  const int nslab = (V + SLAB - 1) / SLAB;
-  const int slab0 = min((int)blockIdx.x * p.slabs_per_wg, nslab), slab1 = min(nslab, slab0 + p.slabs_per_wg);
-  const int dcol = 32 * w + r;        // this lane's output column in both backward products
-  const int bcol = 32 * w + r;        // the batch row (of the tile) whose scores sit on this lane
-  const bool valid_b = bcol < p.Bt;
-  const int brow = min(bcol, p.Bt - 1);
-  const float c_b = valid_b ? fmaf(-p.lse[brow], L2E, log2f(p.scale)) : -INFINITY;
-  const int t_b = valid_b ? min(max(p.target[brow], 0), V - 1) : -1;
-  Tri p1[8], p2[8];
-  load_pred_rows(p1, p.P + (size_t)brow * D, h);
-  // pred[k = b = 16 s + 8 h + j][n = d = dcol]: the B operand of dE (rows past the tile: any valid row, their G is 0)
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = p.P[(size_t)min(16 * s + 8 * h + j, p.Bt - 1) * D + dcol];
-    p2[s] = split8(x);
-  }
-  f32x16 dp[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) dp[i] = f32x16{0.f};
-  float sq = 0.f;
-
-  unsigned char *const g_wr = g_img + (4 * h) * G_PITCH + (32 * w + r) * 2;       // G[v][b], one element
-  unsigned char *const gt_wr = gt_img + (32 * w + r) * GT_PITCH + (4 * h) * 2;    // G^T[b][v], four rows of v
-  const unsigned char *const g_rd = g_img + r * G_PITCH + 16 * h;
-  const unsigned char *const gt_rd = gt_img + r * GT_PITCH + 16 * h;
-
-  Stage st;
-  if (slab0 < slab1) stage_load(st, p.E, slab0 * SLAB, V, tid);
-  for (int sl = slab0; sl < slab1; ++sl) {
-    stage_store_split(st, e_img, tid);
-    __syncthreads();
-    if (sl + 1 < slab1) stage_load(st, p.E, (sl + 1) * SLAB, V, tid);
-    const int vbase = sl * SLAB;
-    const bool full = vbase + SLAB <= V;
-    const int vlim = full ? 0x7fffffff : V;
-
-    // ---- scores of this wave's 32 batch rows; G, split, to LDS in both orientations
-    {
-      const f32x16 acc = slab_scores(e_img, p1, r, h);
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        bf16x4 gq[3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = 8 * q4 + i;                      // + 4 h: catalog row of the slab
-          const int v = vbase + row + 4 * h;
-          float g = fast_exp2(fmaf(acc[4 * q4 + i], L2E, c_b)) - ((v == t_b) ? p.scale : 0.f);
-          g = (v < vlim) ? g : 0.f;
-          __bf16 a, b, c;
-          split3(g, a, b, c);
-          gq[0][i] = a; gq[1][i] = b; gq[2][i] = c;
-          *reinterpret_cast<__bf16 *>(g_wr + row * G_PITCH) = a;
-          *reinterpret_cast<__bf16 *>(g_wr + G_IMG + row * G_PITCH) = b;
-          *reinterpret_cast<__bf16 *>(g_wr + 2 * G_IMG + row * G_PITCH) = c;
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4 *>(gt_wr + t * GT_IMG + (8 * q4) * 2) = gq[t];
-      }
-    }
-    __syncthreads();
-
-    // ---- dE[v][d] = sum_b G[v][b] pred[b][d]   (this wave: columns d = 32 w ..)
-    {
-      f32x16 acc = {0.f};
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        Tri a;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) a.t[t] = *reinterpret_cast<const bf16x8 *>(g_rd + t * G_IMG + 32 * s);
-        acc = mfma6(a, p2[s], acc);
-      }
-      float *const out = p.dE + ((size_t)vbase + 4 * h) * D + dcol;
-      if (RMW) {
-        float old[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-          old[q] = out[(long)min((q & 3) + 8 * (q >> 2), V - 1 - vbase - 4 * h) * D];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] += old[q];
-      }
-      if (full) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          sq = fmaf(acc[q], acc[q], sq);
-          out[(size_t)((q & 3) + 8 * (q >> 2)) * D] = acc[q];
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = (q & 3) + 8 * (q >> 2);
-          if (vbase + row + 4 * h < V) {
-            sq = fmaf(acc[q], acc[q], sq);
-            out[(size_t)row * D] = acc[q];
-          }
-        }
-      }
-    }
-
-    // ---- d_pred[b][d] += sum_v G[v][b] E[v][d]   (this wave: columns d = 32 w .., all 128 batch rows)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      Tri bfrag;
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        uint16_t u[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          u[j] = *reinterpret_cast<const uint16_t *>(e_img + t * E_IMG + (16 * s + 8 * h + j) * E_PITCH + dcol * 2);
-        const u32x4 pk = {(uint32_t)u[0] | ((uint32_t)u[1] << 16), (uint32_t)u[2] | ((uint32_t)u[3] << 16),
-                          (uint32_t)u[4] | ((uint32_t)u[5] << 16), (uint32_t)u[6] | ((uint32_t)u[7] << 16)};
-        bfrag.t[t] = __builtin_bit_cast(bf16x8, pk);
-      }
-#pragma unroll
-      for (int mblk = 0; mblk < 4; ++mblk) {
-        Tri a;
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-          a.t[t] = *reinterpret_cast<const bf16x8 *>(gt_rd + t * GT_IMG + (32 * mblk) * GT_PITCH + 32 * s);
-        dp[mblk] = mfma6(a, bfrag, dp[mblk]);
-      }
-    }
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int mblk = 0; mblk < 4; ++mblk)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int b = 32 * mblk + acc_row(q, h);
-      if (b < p.Bt) atomicAdd(p.d_pred + b * D + dcol, dp[mblk][q]);
-    }
-  if (p.sq_partial) {
-    sq = wave_sum(sq);
-    if (lane == 0) p.sq_partial[(size_t)blockIdx.x * 4 + w] = sq;
-  }
-}
-
-// ---- the same pass with the work cut by ROLE instead of by tile: 8 waves, two per SIMD.
-// bwd_kernel above keeps one wave per SIMD busy with everything in turn -- split E, scores, exp + split G, two
-// products -- and its 356 registers per lane allow no second workgroup on the CU: the matrix pipe idles through
-// every VALU / LDS stretch (6.4 ms at 10 M rows against 2.35 ms of MFMA issue).  Here waves 0..3 PRODUCE (split the
-// next slab, score it, turn the scores into the three G images) while waves 4..7, their SIMD partners, CONSUME
-// (dE and d_pred of the current slab): vector work of one role runs beside matrix work of the other.
-//   phase a   P: split E(s + 1) -> e[next]                 C: dE(s)            <- g
-//   phase b   P: scores(s + 1)  <- e[next]                  C: d_pred(s), block 0      <- gt[cur], e[cur]
-//   phase c   P: G(s + 1) -> g, gt[next]                    C: d_pred(s), blocks 1..3  <- gt[cur], e[cur]
-// E images and G^T images are double-buffered, G single (140 KB of LDS); three barriers per slab, as before.
-constexpr int T_PITCH = 36;             // per consumer wave: a 32 x 32 fp32 tile on its way out, rows 36 floats apart
-constexpr int PC_SCRATCH = 4 * 32 * T_PITCH * 4;
-constexpr int PC_LDS = 2 * 3 * E_IMG + 3 * G_IMG + 2 * 3 * GT_IMG + PC_SCRATCH;      // 158,208 B
-
-template <bool RMW>
-__global__ __launch_bounds__(512) void bwd_pc_kernel(BwdArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char *const e_buf = lds;                                   // [2][3][E_IMG]
-  unsigned char *const g_img = lds + 2 * 3 * E_IMG;                   // [3][G_IMG]
-  unsigned char *const gt_buf = g_img + 3 * G_IMG;                    // [2][3][GT_IMG]
-  float *const t_scratch = reinterpret_cast<float *>(gt_buf + 2 * 3 * GT_IMG);
+  unsigned char *const e_buf = lds;                                   // [3][3][E2_IMG]
+  unsigned char *const gt_buf = lds + 3 * 3 * E2_IMG;                 // [2][3][GT2_IMG]
+  float *const t_scratch = reinterpret_cast<float *>(gt_buf + 2 * 3 * GT2_IMG);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const bool producer = wave < 4;
-  const int w = wave & 3, ptid = tid & 255;
+  const int role = wave >> 2, w = wave & 3;
   const int V = p.V;
   const int nslab = (V + SLAB - 1) / SLAB;
-  const int slab0 = min((int)blockIdx.x * p.slabs_per_wg, nslab), slab1 = min(nslab, slab0 + p.slabs_per_wg);
-  const int n = slab1 - slab0;
+  const SlabWalk wk = slab_walk(blockIdx.x, gridDim.x, p.slabs_per_wg, nslab);
+  const int slab0 = wk.first, step = wk.step, n = wk.n;
   if (n <= 0) {                      // (a workgroup past the end of the catalog: nothing to add, nothing to sum)
-    if (!producer && p.sq_partial && lane == 0) p.sq_partial[(size_t)blockIdx.x * 4 + w] = 0.f;
+    if (role == 2 && p.sq_partial && lane == 0) p.sq_partial[(size_t)blockIdx.x * 4 + w] = 0.f;
     return;
   }
+  const int cg = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;      // transposed-read lane roles
 
-  if (producer) {
-    // ---------------------------------------------------------------- producer waves
-    const int bcol = 32 * w + r;      // the batch row (of the tile) whose scores sit on this lane
+  if (role == 0) {
+    // ------------------------------------------------------------- S waves: scores and G (batch rows 32 w ..)
+    const int bcol = 32 * w + r;
     const bool valid_b = bcol < p.Bt;
     const int brow = min(bcol, p.Bt - 1);
     const float c_b = valid_b ? fmaf(-p.lse[brow], L2E, log2f(p.scale)) : -INFINITY;
     const int t_b = valid_b ? min(max(p.target[brow], 0), V - 1) : -1;
     Tri p1[8];
     load_pred_rows(p1, p.P + (size_t)brow * D, h);
-    unsigned char *const g_wr = g_img + (4 * h) * G_PITCH + (32 * w + r) * 2;
+    const int swz_r = ((r & 3) << 2) | ((r >> 2) & 3);
+    int gt_wr[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) gt_wr[q4] = gt_off(bcol, q4) + 8 * h;
     Stage st;
-    f32x16 acc;
-    auto make_g = [&](int sl, unsigned char *gt_img) {      // scores in acc -> G(sl), split, both orientations
-      unsigned char *const gt_wr = gt_img + (32 * w + r) * GT_PITCH + (4 * h) * 2;
-      const int vbase = sl * SLAB;
-      const int vlim = (vbase + SLAB <= V) ? 0x7fffffff : V;
+    stage_load(st, p.E, slab0 * SLAB, V, tid);
+    stage_store_split_tr(st, e_buf, tid);
+    if (n > 1) stage_load(st, p.E, (slab0 + step) * SLAB, V, tid);
+    SC_STAMP_DECL
+    __syncthreads();       // (slab 0 staged)
+    SC_STAMP_START
+    for (int i = 0; i <= n; ++i) {
+      if (i < n) {
+        const unsigned char *const e_cur = e_buf + (i % 3) * 3 * E2_IMG;
+        unsigned char *const gt_cur = gt_buf + (i & 1) * 3 * GT2_IMG;
+        f32x16 acc = {0.f};
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        bf16x4 gq[3];
+        for (int s = 0; s < 8; ++s) {
+          Tri a;
+          const int o = 256 * r + 16 * ((2 * s + h) ^ swz_r);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = 8 * q4 + i;
-          const int v = vbase + row + 4 * h;
-          float g = ((p.lab & 8) ? acc[4 * q4 + i] * 1e-3f : fast_exp2(fmaf(acc[4 * q4 + i], L2E, c_b))) -
-                    ((v == t_b) ? p.scale : 0.f);
-          g = (v < vlim) ? g : 0.f;
-          __bf16 a, b, c;
-          split3(g, a, b, c);
-          gq[0][i] = a; gq[1][i] = b; gq[2][i] = c;
-          if (!(p.lab & 2)) {
-            *reinterpret_cast<__bf16 *>(g_wr + row * G_PITCH) = a;
-            *reinterpret_cast<__bf16 *>(g_wr + G_IMG + row * G_PITCH) = b;
-            *reinterpret_cast<__bf16 *>(g_wr + 2 * G_IMG + row * G_PITCH) = c;
+          for (int t = 0; t < 3; ++t) a.t[t] = *reinterpret_cast<const bf16x8 *>(e_cur + t * E2_IMG + o);
+          acc = mfma6(a, p1[s], acc);
+        }
+        SC_STAMP(0)
+        const int vbase = (slab0 + i * step) * SLAB;
+        // the target row of a lane lies in this slab for 128 of the catalog's slabs, and only the last slab is ragged:
+        // both corrections are applied under a wave-uniform test, outside the exp / split chains
+        float g[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) g[q] = fast_exp2(fmaf(acc[q], L2E, c_b));
+        const int t_rel = t_b - vbase - 4 * h;                 // the target as a row of this lane's 16: (q & 3) + 8 (q >> 2)
+        if (__builtin_amdgcn_ballot_w64(t_rel >= 0 && t_rel < SLAB - 4 * h) != 0 || vbase + SLAB > V) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2);
+            g[q] -= (row == t_rel) ? p.scale : 0.f;
+            g[q] = (vbase + row + 4 * h < V) ? g[q] : 0.f;
           }
         }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4 *>(gt_wr + t * GT_IMG + (8 * q4) * 2) = gq[t];
+        for (int q4 = 0; q4 < 4; ++q4) {
+          bf16x4 gq[3];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            __bf16 a, b, c;
+            split3(g[4 * q4 + k], a, b, c);
+            gq[0][k] = a; gq[1][k] = b; gq[2][k] = c;
+          }
+#pragma unroll
+          for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4 *>(gt_cur + t * GT2_IMG + gt_wr[q4]) = gq[t];
+        }
+        SC_STAMP(1)
       }
-    };
-    // prologue: slab 0 scored and turned into G before the first consumer phase
-    stage_load(st, p.E, slab0 * SLAB, V, ptid);
-    stage_store_split(st, e_buf, ptid);
-    if (n > 1) stage_load(st, p.E, (slab0 + 1) * SLAB, V, ptid);
-    __syncthreads();
-    acc = slab_scores(e_buf, p1, r, h);
-    make_g(slab0, gt_buf);
-    __syncthreads();
-    for (int i = 0; i < n; ++i) {
-      const bool more = i + 1 < n;
-      unsigned char *const e_next = e_buf + ((i + 1) & 1) * 3 * E_IMG;
-      // phase a: split slab i + 1 (its fp32 rows arrived during the previous phases), fetch slab i + 2
-      if (more) stage_store_split(st, e_next, ptid);
-      if (i + 2 < n) stage_load(st, p.E, (slab0 + i + 2) * SLAB, V, ptid);
+      if (i + 1 < n) {
+        SC_WAIT_VM
+        SC_STAMP(6)
+        stage_store_split_tr(st, e_buf + ((i + 1) % 3) * 3 * E2_IMG, tid);
+        if (i + 2 < n) stage_load(st, p.E, (slab0 + (i + 2) * step) * SLAB, V, tid);
+        SC_STAMP(2)
+      }
       __syncthreads();
-      // phase b: scores of slab i + 1
-      if (more) acc = slab_scores(e_next, p1, r, h);
-      __syncthreads();
-      // phase c: G of slab i + 1
-      if (more) make_g(slab0 + i + 1, gt_buf + ((i + 1) & 1) * 3 * GT_IMG);
-      __syncthreads();
+      SC_STAMP(3)
     }
+    SC_STAMP_DUMP(1)
     return;
   }
 
-  // ------------------------------------------------------------------ consumer waves
-  const int dcol = 32 * w + r;        // this lane's output column in both backward products
+  if (role == 1) {
+    // ------------------------------------------------------------- D waves: staging and d_pred (columns d = 32 w ..)
+    f32x16 dp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dp[i] = f32x16{0.f};
+    // E^T fragment of (k-step s', half jj): rows v = 16 s' + 8 h + 4 jj + q, columns d = 32 w + 16 cg + 4 pp ..
+    int et_off[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) et_off[jj] = e_off(8 * h + 4 * jj + tq, 4 * w + 2 * cg + (tp >> 1)) + 8 * (tp & 1);
+    // G^T row fragment of (block mblk, k-step s'): chunk 2 s' + h of row b = 32 mblk + r
+    int ga_off[2];
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) ga_off[sp] = gt_off(r, 2 * sp + h);
+    SC_STAMP_DECL
+    __syncthreads();
+    SC_STAMP_START
+    for (int i = 0; i <= n; ++i) {
+      if (i >= 1) {
+        const unsigned char *const e_prev = e_buf + ((i - 1) % 3) * 3 * E2_IMG;
+        const unsigned char *const gt_prev = gt_buf + ((i - 1) & 1) * 3 * GT2_IMG;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          Tri bf;
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            bf.t[t] = lds_tr8(e_prev + t * E2_IMG + 4096 * sp + et_off[0], e_prev + t * E2_IMG + 4096 * sp + et_off[1]);
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) {
+            Tri a;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+              a.t[t] = *reinterpret_cast<const bf16x8 *>(gt_prev + t * GT2_IMG + 2048 * mb + ga_off[sp]);
+            dp[mb] = mfma6(a, bf, dp[mb]);
+          }
+        }
+      }
+      SC_STAMP(0)
+      __syncthreads();
+      SC_STAMP(3)
+    }
+    SC_STAMP_DUMP(1)
+    const int dcol = 32 * w + r;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int b = 32 * mb + acc_row(q, h);
+        if (b < p.Bt) atomicAdd(p.d_pred + b * D + dcol, dp[mb][q]);
+      }
+    return;
+  }
+
+  // ------------------------------------------------------------------ T waves: dE (columns d = 32 w ..)
+  const int dcol = 32 * w + r;
   Tri p2[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
@@ -681,58 +682,30 @@ __global__ __launch_bounds__(512) void bwd_pc_kernel(BwdArgs p) {
     for (int j = 0; j < 8; ++j) x[j] = p.P[(size_t)min(16 * s + 8 * h + j, p.Bt - 1) * D + dcol];
     p2[s] = split8(x);
   }
-  f32x16 dp[4];
+  // G^T fragment of (k-step s, half jj): rows b = 16 s + 8 h + 4 jj + q, columns v = 16 cg + 4 pp ..
+  int gt_rd[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dp[i] = f32x16{0.f};
+  for (int jj = 0; jj < 2; ++jj) gt_rd[jj] = gt_off(8 * h + 4 * jj + tq, 2 * cg + (tp >> 1)) + 8 * (tp & 1);
   float sq = 0.f;
-  const unsigned char *const g_rd = g_img + r * G_PITCH + 16 * h;
-  auto dpred_blocks = [&](const unsigned char *e_img, const unsigned char *gt_img, const int m0, const int m1) {
-    const unsigned char *const gt_rd = gt_img + r * GT_PITCH + 16 * h;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      Tri bfrag;
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        if (p.lab & 4) {
-          bfrag.t[t] = *reinterpret_cast<const bf16x8 *>(e_img + t * E_IMG + r * E_PITCH + 32 * s + 16 * h);
-          continue;
-        }
-        uint16_t u[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          u[j] = *reinterpret_cast<const uint16_t *>(e_img + t * E_IMG + (16 * s + 8 * h + j) * E_PITCH + dcol * 2);
-        const u32x4 pk = {(uint32_t)u[0] | ((uint32_t)u[1] << 16), (uint32_t)u[2] | ((uint32_t)u[3] << 16),
-                          (uint32_t)u[4] | ((uint32_t)u[5] << 16), (uint32_t)u[6] | ((uint32_t)u[7] << 16)};
-        bfrag.t[t] = __builtin_bit_cast(bf16x8, pk);
-      }
-#pragma unroll
-      for (int mblk = 0; mblk < 4; ++mblk) {
-        if (mblk < m0 || mblk >= m1) continue;
-        Tri a;
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-          a.t[t] = *reinterpret_cast<const bf16x8 *>(gt_rd + t * GT_IMG + (32 * mblk) * GT_PITCH + 32 * s);
-        dp[mblk] = mfma6(a, bfrag, dp[mblk]);
-      }
-    }
-  };
-  __syncthreads();       // (producer prologue: slab 0 staged)
-  __syncthreads();       // (producer prologue: G of slab 0 in place)
-  for (int i = 0; i < n; ++i) {
-    const int vbase = (slab0 + i) * SLAB;
-    const bool full = vbase + SLAB <= V;
-    const unsigned char *const e_cur = e_buf + (i & 1) * 3 * E_IMG;
-    const unsigned char *const gt_cur = gt_buf + (i & 1) * 3 * GT_IMG;
-    // phase a: dE[v][d] = sum_b G[v][b] pred[b][d]   (this wave: columns d = 32 w ..)
-    {
+  SC_STAMP_DECL
+  __syncthreads();
+  SC_STAMP_START
+  for (int i = 0; i <= n; ++i) {
+    if (i >= 1) {
+      // dE[v][d] = sum_b G[v][b] pred[b][d] of slab i - 1
+      const unsigned char *const gt_prev = gt_buf + ((i - 1) & 1) * 3 * GT2_IMG;
+      const int vbase = (slab0 + (i - 1) * step) * SLAB;
+      const bool full = vbase + SLAB <= V;
       f32x16 acc = {0.f};
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         Tri a;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) a.t[t] = *reinterpret_cast<const bf16x8 *>(g_rd + t * G_IMG + 32 * s);
+        for (int t = 0; t < 3; ++t)
+          a.t[t] = lds_tr8(gt_prev + t * GT2_IMG + 1024 * s + gt_rd[0], gt_prev + t * GT2_IMG + 1024 * s + gt_rd[1]);
         acc = mfma6(a, p2[s], acc);
       }
+      SC_STAMP(0)
       float *const out = p.dE + ((size_t)vbase + 4 * h) * D + dcol;
       if (RMW) {
         float old[16];
@@ -742,29 +715,18 @@ __global__ __launch_bounds__(512) void bwd_pc_kernel(BwdArgs p) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] += old[q];
       }
-      // The tile has its column on the lane: stored as it lies that is 16 four-byte stores of 128-byte segments per
-      // lane (store ISSUE, 0.6 ms of the pass at 10 M rows).  Through a wave-private LDS scratch it leaves as four
-      // 16-byte stores per lane (8 rows x 128 B per wave instruction).
-      if (full && !RMW) {
+      if (full && !RMW) {            // through a wave-private scratch: four 16-byte stores per lane
         float *const sc = t_scratch + w * (32 * T_PITCH);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           sq = fmaf(acc[q], acc[q], sq);
           sc[((q & 3) + 8 * (q >> 2) + 4 * h) * T_PITCH + r] = acc[q];
         }
-        if (!(p.lab & 1)) {
 #pragma unroll
-          for (int i4 = 0; i4 < 4; ++i4) {
-            const int idx = i4 * 64 + lane, row = idx >> 3, c4 = idx & 7;
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(sc + row * T_PITCH + 4 * c4);
-            *reinterpret_cast<f32x4 *>(p.dE + ((size_t)vbase + row) * D + 32 * w + 4 * c4) = t;
-          }
-        }
-      } else if (full) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          sq = fmaf(acc[q], acc[q], sq);
-          out[(size_t)((q & 3) + 8 * (q >> 2)) * D] = acc[q];
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const int idx = i4 * 64 + lane, row = idx >> 3, c4 = idx & 7;
+          const f32x4 t = *reinterpret_cast<const f32x4 *>(sc + row * T_PITCH + 4 * c4);
+          *reinterpret_cast<f32x4 *>(p.dE + ((size_t)vbase + row) * D + 32 * w + 4 * c4) = t;
         }
       } else {
 #pragma unroll
@@ -776,23 +738,12 @@ __global__ __launch_bounds__(512) void bwd_pc_kernel(BwdArgs p) {
           }
         }
       }
+      SC_STAMP(1)
     }
     __syncthreads();
-    // phases b, c: d_pred[b][d] += sum_v G[v][b] E[v][d]   (this wave: columns d = 32 w .., two 32-row blocks each)
-    // (one block beside the producers' 48 score MFMAs, three beside their exp + split: 60 / 36 MFMAs per SIMD in
-    // phases b / c instead of 72 / 24)
-    dpred_blocks(e_cur, gt_cur, 0, 1);
-    __syncthreads();
-    dpred_blocks(e_cur, gt_cur, 1, 4);
-    __syncthreads();
+    SC_STAMP(3)
   }
-#pragma unroll
-  for (int mblk = 0; mblk < 4; ++mblk)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int b = 32 * mblk + acc_row(q, h);
-      if (b < p.Bt) atomicAdd(p.d_pred + b * D + dcol, dp[mblk][q]);
-    }
+  SC_STAMP_DUMP(1)
   if (p.sq_partial) {
     sq = wave_sum(sq);
     if (lane == 0) p.sq_partial[(size_t)blockIdx.x * 4 + w] = sq;
@@ -810,22 +761,10 @@ bool use_split(int V) {
   }();
   return min_rows > 0 && V >= min_rows;
 }
-int lab_bits() {
-  const char *e = getenv("MTAM_SCORE32_LAB");      // read at every call: the lab flips it between timings
-  return e ? atoi(e) : 0;
-}
-bool use_pc() {
-  static const bool on = [] {
-    const char *e = getenv("MTAM_SCORE32_PC");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-
 int slabs_of(int V) { return (V + SLAB - 1) / SLAB; }
 // Workgroups per batch tile: each owns a contiguous range of slabs and flushes its [128, 128] share of d_pred
 // ONCE, by atomics (64 KB each at the ~1.3 TB/s float-atomic rate: 2,048 workgroups = 100 us, 512 = 25 us).
-// The backward kernel holds 336 registers per lane = one workgroup per CU, so 512 ranges are two rounds over
+// The backward kernels run one workgroup per CU (registers, or 138 KB of LDS), so 512 ranges are two rounds over
 // the 256 CUs.  MTAM_SCORE32_MAX_WGS overrides (read once).
 int max_wgs() {
   static const int v = [] {
@@ -838,10 +777,20 @@ int max_wgs() {
 int chunks_of(int V) { return max(1, min(slabs_of(V), max_wgs())); }
 // the forward (lse) pass has nothing to flush: up to 2,048 ranges, so that three workgroups per CU keep loads in flight
 int lse_chunks_of(int V) { return max(1, min(slabs_of(V), 2048)); }
-int lse_slabs_per_wg_of(int V) { return (slabs_of(V) + lse_chunks_of(V) - 1) / lse_chunks_of(V); }
-int lse_grid_of(int V) { return (slabs_of(V) + lse_slabs_per_wg_of(V) - 1) / lse_slabs_per_wg_of(V); }
-int slabs_per_wg_of(int V) { return (slabs_of(V) + chunks_of(V) - 1) / chunks_of(V); }
-int grid_of(int V) { return (slabs_of(V) + slabs_per_wg_of(V) - 1) / slabs_per_wg_of(V); }
+// the split kernels walk the slabs cyclically (x3::slab_walk; slabs_per_wg = 0 says so) unless MTAM_SCORE32_CYCLIC=0
+bool cyclic(int V) {
+  static const bool on = [] {
+    const char *e = getenv("MTAM_SCORE32_CYCLIC");
+    return !(e && e[0] == '0');
+  }();
+  return on && use_split(V);
+}
+int lse_slabs_per_wg_of(int V) { return cyclic(V) ? 0 : (slabs_of(V) + lse_chunks_of(V) - 1) / lse_chunks_of(V); }
+int lse_grid_of(int V) {
+  return cyclic(V) ? lse_chunks_of(V) : (slabs_of(V) + lse_slabs_per_wg_of(V) - 1) / lse_slabs_per_wg_of(V);
+}
+int slabs_per_wg_of(int V) { return cyclic(V) ? 0 : (slabs_of(V) + chunks_of(V) - 1) / chunks_of(V); }
+int grid_of(int V) { return cyclic(V) ? chunks_of(V) : (slabs_of(V) + slabs_per_wg_of(V) - 1) / slabs_per_wg_of(V); }
 
 }  // namespace
 
@@ -876,18 +825,12 @@ extern "C" int mtam_score32_bwd(const float *E, const float *pred, const float *
   if (split) {
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(x3::bwd_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, x3::BWD_LDS);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(x3::bwd_tr3_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, x3::TR3_LDS);
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(x3::bwd_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, x3::BWD_LDS);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(x3::bwd_pc_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, x3::PC_LDS);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(x3::bwd_pc_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, x3::PC_LDS);
-      MTAM_CHECK_ARG(e == hipSuccess, "score32_bwd: cannot reserve %d bytes of LDS: %s", x3::BWD_LDS,
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(x3::bwd_tr3_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, x3::TR3_LDS);
+      MTAM_CHECK_ARG(e == hipSuccess, "score32_bwd: cannot reserve %d bytes of LDS: %s", x3::TR3_LDS,
                      hipGetErrorString(e));
       attr_set = true;
     }
@@ -897,15 +840,11 @@ extern "C" int mtam_score32_bwd(const float *E, const float *pred, const float *
   for (int tile = 0; tile < ntile; ++tile) {
     const long b0 = (long)tile * BT;
     BwdArgs a{E, pred + b0 * D, lse + b0, target + b0, V, (int)min((long)BT, B - b0), slabs_per_wg_of(V), scale,
-              d_pred + b0 * D, dE, tile == ntile - 1 ? sq_partial : nullptr, lab_bits()};
-    if (split && use_pc() && tile == 0)
-      hipLaunchKernelGGL(x3::bwd_pc_kernel<false>, dim3(grid_of(V)), dim3(512), x3::PC_LDS, st, a);
-    else if (split && use_pc())
-      hipLaunchKernelGGL(x3::bwd_pc_kernel<true>, dim3(grid_of(V)), dim3(512), x3::PC_LDS, st, a);
-    else if (split && tile == 0)
-      hipLaunchKernelGGL(x3::bwd_kernel<false>, dim3(grid_of(V)), dim3(256), x3::BWD_LDS, st, a);
+              d_pred + b0 * D, dE, tile == ntile - 1 ? sq_partial : nullptr};
+    if (split && tile == 0)
+      hipLaunchKernelGGL(x3::bwd_tr3_kernel<false>, dim3(grid_of(V)), dim3(768), x3::TR3_LDS, st, a);
     else if (split)
-      hipLaunchKernelGGL(x3::bwd_kernel<true>, dim3(grid_of(V)), dim3(256), x3::BWD_LDS, st, a);
+      hipLaunchKernelGGL(x3::bwd_tr3_kernel<true>, dim3(grid_of(V)), dim3(768), x3::TR3_LDS, st, a);
     else if (tile == 0)
       hipLaunchKernelGGL(score32_bwd_kernel<false>, dim3(grid_of(V)), dim3(256), 0, st, a);
     else

@@ -1,6 +1,5 @@
-"""Developer timing of the fp32 logits-free scoring pair at large V (GPU box).  Where a slab's cycles go:
-tools/score_lab.hip.
-usage: score32_time.py V [B]"""
+"""Three launches of the fp32 logits-free scoring pair at V rows (run under rocprofv3 --pmc ...; GPU box).
+usage: score32_pmc.py V [B]"""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -20,20 +19,8 @@ partial = torch.zeros(ops.score32_partials(B, V), device="cuda")
 sq = torch.zeros(ops.score32_sq_partials(V), device="cuda")
 d_pred = torch.zeros((B, D), device="cuda")
 dE = torch.empty((V, D), device="cuda")
-
-
-def timeit(fn, n=5):
-    fn()
+for _ in range(3):
+    ops.score32_lse(E, P, tgt, B, V, partial, lse, ce)
+    ops.score32_bwd(E, P, lse, tgt, B, V, 1.0 / B, d_pred, dE, sq)
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(n):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / n
-
-
-print("V = %d, B = %d" % (V, B))
-print("lse pass                 %.3f ms" % timeit(lambda: ops.score32_lse(E, P, tgt, B, V, partial, lse, ce)))
-print("backward                 %.3f ms" % timeit(lambda: ops.score32_bwd(E, P, lse, tgt, B, V, 1.0 / B, d_pred, dE, sq)))
+print("done")
