@@ -63,7 +63,13 @@ const char *mtam_arch(void);     /* "gfx950" */
  *                        32x32 quadrant: mtam_gemm_sq_partials(M, N) floats whose sum is ||C||^2
  *                        (the dense item gradient's share of tf.global_norm, Model/base_model.py:294)
  * aux_in / aux_out share ld_aux.  split_k > 1 is only valid with ATOMIC.
+ * MTAM_GEMM_SPLIT_BF16 OR-ed into `epilogue`: the products are formed on the bf16 matrix cores from the operands
+ * split three ways (x = x1 + x2 + x3, six partial products, fp32 accumulation: fp32-equivalent, 2.7 x the matrix
+ * rate); the training step's GEMMs ask for it, the evaluation logits (whose ranking contract is the k-ordered
+ * fmaf chain) do not.  The grouped weight-gradient launches always use it.  MTAM_GEMM_SPLIT=0 in the environment
+ * turns it off everywhere.
  */
+enum { MTAM_GEMM_SPLIT_BF16 = 0x100 };
 enum {
   MTAM_EPI_STORE = 0,
   MTAM_EPI_BIAS = 1,

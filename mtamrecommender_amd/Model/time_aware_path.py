@@ -338,7 +338,7 @@ class TimeAwarePath(object):
                             bt.lse, bt.ce)
             return
         if self.score_dtype == "f32":
-            ops.gemm(bt.pred, self.tables["item"], bt.logits_store, trans_b=True)
+            ops.gemm(bt.pred, self.tables["item"], bt.logits_store, trans_b=True, split=False)
             return
         ops.f32_to_bf16(bt.pred.view(-1), bt.pred16.view(-1))
         if training:
@@ -661,7 +661,7 @@ class TimeAwarePath(object):
             if self.score_dtype == "f32":
                 # rows [col0, col0 + width) of the item table: every score is the same k-ordered fmaf chain
                 # as in the one-piece product
-                ops.gemm(bt.pred, self.tables["item"][col0:col0 + width], bt.eval_slab, trans_b=True, ldc=W)
+                ops.gemm(bt.pred, self.tables["item"][col0:col0 + width], bt.eval_slab, trans_b=True, ldc=W, split=False)
             else:
                 ops.score16_logits(self.item16[col0:col0 + width], bt.pred16, bt.B, width, bt.eval_slab, W)
             ops.topk_stream_slab(bt.eval_slab, W, bt.B, col0, width, V, k, bt.topk_ws)

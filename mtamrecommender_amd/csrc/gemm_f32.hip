@@ -12,6 +12,8 @@
 // tile kt+1 moves registers -> LDS and tile kt+2's global loads are issued
 // (straight-line 16-B loads on the wave-uniform fast path), one barrier per tile.
 #include "common.h"
+#include "split_bf16.h"
+#include <stdlib.h>
 
 #ifndef GEMM_STAMP          // tools/gemm_lab.hip defines these to read where a kernel's cycles go
 #define GEMM_STAMP(i)
@@ -129,6 +131,47 @@ __device__ __forceinline__ void store_ccontig(float *__restrict__ S, const float
 
 template <int E> constexpr int tile_floats() { return BK * (E + 4); }   // one operand tile in LDS
 constexpr int TILE_FLOATS = tile_floats<64>();
+
+// ---- split-bf16 operands (X3 = true in gemm_tile): fp32 products from six bf16 MFMAs (csrc/split_bf16.h), 2.7 x the
+// matrix rate of v_mfma_f32_32x32x2_f32.  A staged 64 x 32 operand tile becomes THREE bf16 images of 4 KB, written as
+// 8-byte pieces in the orientation the source has and read as the MFMA wants them:
+//   source k-contiguous (src[row][k]):  image [64 rows][32 k] (64-byte rows); a fragment (row r, 8 k) is one ds_read_b128
+//   source row-contiguous (src[k][c]):  image [32 k][64 c] (128-byte rows); a fragment (column c, 8 k) is gathered DOWN
+//                                        the image by two ds_read_b64_tr_b16
+// with 16-byte chunks swizzled so that the writes, the row reads and the transposed reads are all conflict-free.
+using namespace split_bf16;
+constexpr int X3_IMG = 4096;                      // bytes per image
+constexpr int X3_TILE_FLOATS = 3 * X3_IMG / 4;    // one operand tile (three images), in floats
+__device__ __forceinline__ int kimg_off(int row, int ch) { return 64 * row + 16 * (ch ^ ((row >> 2) & 3)); }     // ch 0..3
+__device__ __forceinline__ int cimg_off(int k, int ch) { return 128 * k + 16 * (ch ^ (((k >> 1) & 1) << 2)); }  // ch 0..7
+// registers of load_kcontig<., 64> -> images
+__device__ __forceinline__ void store_kcontig_x3(unsigned char *img, const float4 (&reg)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = t + 256 * i, r = idx >> 3, piece = idx & 7;
+    const float x[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+    bf16x4 q[3];
+    split4(x, q);
+    unsigned char *const dst = img + kimg_off(r, piece >> 1) + 8 * (piece & 1);
+#pragma unroll
+    for (int im = 0; im < 3; ++im) *reinterpret_cast<bf16x4 *>(dst + im * X3_IMG) = q[im];
+  }
+}
+// registers of load_ccontig<., 64> -> images
+__device__ __forceinline__ void store_ccontig_x3(unsigned char *img, const float4 (&reg)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = t + 256 * i, k = idx >> 4, piece = idx & 15;
+    const float x[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+    bf16x4 q[3];
+    split4(x, q);
+    unsigned char *const dst = img + cimg_off(k, piece >> 1) + 8 * (piece & 1);
+#pragma unroll
+    for (int im = 0; im < 3; ++im) *reinterpret_cast<bf16x4 *>(dst + im * X3_IMG) = q[im];
+  }
+}
 
 // One wave's 32x32 accumulator -> C with the fused epilogue.
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -258,12 +301,13 @@ __device__ __forceinline__ float store_acc_rows(const GemmArgs &p, const f32x16 
   return sq;
 }
 
-template <int MW, bool TA, bool TB, int EPI>
+template <int MW, bool TA, bool TB, int EPI, bool X3 = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *Bs, int tile, int kslice) {
+  static_assert(!X3 || MW == 1, "split-bf16 operands: 64 x 64 tiles only");
   constexpr int EA = 64 * MW;                   // A-tile rows
   constexpr int LDA_S = TA ? EA + 4 : EA + 1;
   constexpr int LDB_S = TB ? BN + 1 : BN + 4;
-  constexpr int A_FLOATS = tile_floats<EA>(), B_FLOATS = tile_floats<BN>();
+  constexpr int A_FLOATS = X3 ? X3_TILE_FLOATS : tile_floats<EA>(), B_FLOATS = X3 ? X3_TILE_FLOATS : tile_floats<BN>();
   constexpr int BM = EA;
 
   const int lane = threadIdx.x & 63;
@@ -285,7 +329,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
   for (int i = 0; i < 16; ++i) acc[i] = acc2[i] = 0.f;
 
   float4 ra[EA / 32], rb[BN / 32];
-  auto load_tiles = [&](int k0) {
+  auto load_tiles = [&](int k0) __attribute__((always_inline)) {
     const bool fullK = (k0 + BK <= kend);
     if (fullA && fullK) {
       if (TA) load_ccontig<true, EA>(Asrc, lda, p.M, m0, k0, kend, ra);
@@ -302,10 +346,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
       else    load_ccontig<false, BN>(Bsrc, ldb, p.N, n0, k0, kend, rb);
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_set = [&](int buf, const float4 (&qa)[EA / 32], const float4 (&qb)[BN / 32]) __attribute__((always_inline)) {
     float *a = As + buf * A_FLOATS, *b = Bs + buf * B_FLOATS;
-    if (TA) store_ccontig<EA>(a, ra); else store_kcontig<EA>(a, ra);
-    if (TB) store_kcontig<BN>(b, rb); else store_ccontig<BN>(b, rb);
+    if constexpr (X3) {
+      unsigned char *ai = reinterpret_cast<unsigned char *>(a), *bi = reinterpret_cast<unsigned char *>(b);
+      if (TA) store_ccontig_x3(ai, qa); else store_kcontig_x3(ai, qa);
+      if (TB) store_kcontig_x3(bi, qb); else store_ccontig_x3(bi, qb);
+    } else {
+      if (TA) store_ccontig<EA>(a, qa); else store_kcontig<EA>(a, qa);
+      if (TB) store_kcontig<BN>(b, qb); else store_ccontig<BN>(b, qb);
+    }
   };
 
   for (int src = 0; src < (p.A2 ? 2 : 1); ++src) {
@@ -319,7 +369,47 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int a_off = (lane >> 5) * LDA_S + wm * (32 * MW) + (lane & 31);
     const int b_off = (lane >> 5) * LDB_S + wn * 32 + (lane & 31);
-    auto multiply = [&](int kt) {
+    GEMM_STAMP_DECL;
+    // split-bf16 fragment addresses (bytes into an operand's first image): row-read or transposed-read form
+    const int cgl = (lane >> 4) & 1, tql = (lane >> 2) & 3, tpl = lane & 3, hl = lane >> 5, rl = lane & 31;
+    int xa[2][2], xb[2][2];       // [k-step][half]; the row-read form uses [.][0] only
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (TA) {
+        xa[ks][0] = cimg_off(16 * ks + 8 * hl + tql, 4 * wm + 2 * cgl + (tpl >> 1)) + 8 * (tpl & 1);
+        xa[ks][1] = cimg_off(16 * ks + 8 * hl + 4 + tql, 4 * wm + 2 * cgl + (tpl >> 1)) + 8 * (tpl & 1);
+      } else {
+        xa[ks][0] = xa[ks][1] = kimg_off(32 * wm + rl, 2 * ks + hl);
+      }
+      if (!TB) {
+        xb[ks][0] = cimg_off(16 * ks + 8 * hl + tql, 4 * wn + 2 * cgl + (tpl >> 1)) + 8 * (tpl & 1);
+        xb[ks][1] = cimg_off(16 * ks + 8 * hl + 4 + tql, 4 * wn + 2 * cgl + (tpl >> 1)) + 8 * (tpl & 1);
+      } else {
+        xb[ks][0] = xb[ks][1] = kimg_off(32 * wn + rl, 2 * ks + hl);
+      }
+    }
+    auto multiply_x3 = [&](int kt) __attribute__((always_inline)) {
+      const unsigned char *ai = reinterpret_cast<const unsigned char *>(As + (kt & 1) * A_FLOATS);
+      const unsigned char *bi = reinterpret_cast<const unsigned char *>(Bs + (kt & 1) * B_FLOATS);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        Tri fa, fb;
+#pragma unroll
+        for (int im = 0; im < 3; ++im) {
+          if (TA) fa.t[im] = lds_tr8(ai + im * X3_IMG + xa[ks][0], ai + im * X3_IMG + xa[ks][1]);
+          else    fa.t[im] = *reinterpret_cast<const bf16x8 *>(ai + im * X3_IMG + xa[ks][0]);
+          if (!TB) fb.t[im] = lds_tr8(bi + im * X3_IMG + xb[ks][0], bi + im * X3_IMG + xb[ks][1]);
+          else     fb.t[im] = *reinterpret_cast<const bf16x8 *>(bi + im * X3_IMG + xb[ks][0]);
+        }
+        acc = mfma6(fa, fb, acc);
+      }
+      GEMM_STAMP(2);
+    };
+    auto multiply = [&](int kt) __attribute__((always_inline)) {
+      if constexpr (X3) {
+        multiply_x3(kt);
+        return;
+      }
       const float *a_s = As + (kt & 1) * A_FLOATS + a_off;
       const float *b_s = Bs + (kt & 1) * B_FLOATS + b_off;
       float fa[BK / 2], fa2[BK / 2], fb[BK / 2];
@@ -337,55 +427,60 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
       }
       GEMM_STAMP(2);
     };
-    GEMM_STAMP_DECL;
     if (fullA && fullB && (kend - kbeg) % BK == 0) {
       // Every tile in range: a straight-line loop body.  The 16 MFMAs of a k-tile are one dependent
       // chain (a new one issues every ~84 cycles, tools/gemm_lab.hip), so the next tile's LDS writes
       // and the global loads of the tile after it are placed INTO those gaps instead of after the
       // chain, where a lone wave per SIMD ran them un-overlapped (1,100 of 2,900 cycles per k-tile).
-      auto load_fast = [&](int k0) {
-        if (TA) load_ccontig<true, EA>(Asrc, lda, p.M, m0, k0, kend, ra);
-        else    load_kcontig<true, EA>(Asrc, lda, p.M, m0, k0, kend, ra);
-        if (TB) load_kcontig<true, BN>(Bsrc, ldb, p.N, n0, k0, kend, rb);
-        else    load_ccontig<true, BN>(Bsrc, ldb, p.N, n0, k0, kend, rb);
-      };
-      // ds_write2_b32 pairs / ds_write_b128 per k-tile
-      constexpr int N_DSW = (TA ? 2 : 4) * MW + (TB ? 4 : 2);
-      load_fast(kbeg);
-      store_tiles(0);
-      if (nk > 1) load_fast(kbeg + BK);
-      __syncthreads();
-      int kt = 0;
-      for (; kt + 2 < nk; ++kt) {
-        GEMM_STAMP(0);
-        multiply(kt);
-        store_tiles((kt + 1) & 1);
-        load_fast(kbeg + (kt + 2) * BK);
+      {
+        // (A second register set, each tile's loads issued two iterations ahead of its LDS write, measured no
+        // faster on the step-sized products -- 28.7 against 27.0 us for the weight gradients: a k-tile of the
+        // split path is paced by its own chain fragment reads -> 12 MFMAs -> split + LDS writes -> barrier with
+        // one wave per SIMD, tools/gemm_lab.hip, not by the round trip of its operands.)
+        // ds_write2_b32 pairs / ds_write_b128 per k-tile
+        constexpr int N_DSW = (TA ? 2 : 4) * MW + (TB ? 4 : 2);
+        auto load_one = [&](int k0) __attribute__((always_inline)) {
+          if (TA) load_ccontig<true, EA>(Asrc, lda, p.M, m0, k0, kend, ra);
+          else    load_kcontig<true, EA>(Asrc, lda, p.M, m0, k0, kend, ra);
+          if (TB) load_kcontig<true, BN>(Bsrc, ldb, p.N, n0, k0, kend, rb);
+          else    load_ccontig<true, BN>(Bsrc, ldb, p.N, n0, k0, kend, rb);
+        };
+        load_one(kbeg);
+        store_set(0, ra, rb);
+        if (nk > 1) load_one(kbeg + BK);
+        __syncthreads();
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) {
+          GEMM_STAMP(0);
+          multiply(kt);
+          store_set((kt + 1) & 1, ra, rb);
+          load_one(kbeg + (kt + 2) * BK);
 #pragma unroll
-        for (int i = 0; i < BK / 2; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, MW, 0);                      // one MFMA per chain
-          if (i >= 2 && i < 2 + N_DSW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-          if (i >= 10 && i < 12 + 2 * MW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+          for (int i = 0; i < (X3 ? 0 : BK / 2); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MW, 0);                      // one MFMA per chain
+            if (i >= 2 && i < 2 + N_DSW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+            if (i >= 10 && i < 12 + 2 * MW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+          }
+          GEMM_STAMP(3);
+          __syncthreads();
+          GEMM_STAMP(4);
         }
-        GEMM_STAMP(3);
-        __syncthreads();
-        GEMM_STAMP(4);
-      }
-      for (; kt < nk; ++kt) {
-        multiply(kt);
-        if (kt + 1 < nk) store_tiles((kt + 1) & 1);
-        __syncthreads();
+        for (; kt < nk; ++kt) {
+          multiply(kt);
+          if (kt + 1 < nk) store_set((kt + 1) & 1, ra, rb);
+          __syncthreads();
+        }
       }
     } else {
       load_tiles(kbeg);
-      store_tiles(0);
+      store_set(0, ra, rb);
       if (nk > 1) load_tiles(kbeg + BK);
       __syncthreads();
       for (int kt = 0; kt < nk; ++kt) {
         GEMM_STAMP(0);
         multiply(kt);
         if (kt + 1 < nk) {
-          store_tiles((kt + 1) & 1);                       // registers hold tile kt+1 (loaded one step ago)
+          store_set((kt + 1) & 1, ra, rb);                       // registers hold tile kt+1 (loaded one step ago)
           if (kt + 2 < nk) load_tiles(kbeg + (kt + 2) * BK);
         }
         GEMM_STAMP(3);
@@ -413,10 +508,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &p, float *As, float *B
   }
 }
 
-template <int MW, bool TA, bool TB, int EPI>
+template <int MW, bool TA, bool TB, int EPI, bool X3>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float As[2 * tile_floats<64 * MW>()];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float As[2 * (X3 ? X3_TILE_FLOATS : tile_floats<64 * MW>())];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * (X3 ? X3_TILE_FLOATS : TILE_FLOATS)];
   // 1-D tile index (grid.y is capped at 65535; V/64 is not), split-K slice on grid.y
   if (p.heads > 0) {                       // batched: grid.y is the batch index, no split-K
     GemmArgs q = p;
@@ -424,10 +519,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     q.A += z0 * p.sA0 + z1 * p.sA1;
     q.B += z0 * p.sB0 + z1 * p.sB1;
     q.C += z0 * p.sC0 + z1 * p.sC1;
-    gemm_tile<MW, TA, TB, EPI>(q, As, Bs, blockIdx.x, 0);
+    gemm_tile<MW, TA, TB, EPI, X3>(q, As, Bs, blockIdx.x, 0);
     return;
   }
-  gemm_tile<MW, TA, TB, EPI>(p, As, Bs, blockIdx.x, blockIdx.y);
+  gemm_tile<MW, TA, TB, EPI, X3>(p, As, Bs, blockIdx.x, blockIdx.y);
 }
 
 // Grouped weight-gradient form: up to MTAM_MAX_GROUP independent C += A^T B problems
@@ -479,9 +574,10 @@ struct WeightGradArgs {
   int gemm_blocks;
 };
 
+template <bool X3>
 __global__ __launch_bounds__(256) void weight_grads_kernel(WeightGradArgs wa) {
-  __shared__ __attribute__((aligned(16))) float As[2 * TILE_FLOATS];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float As[2 * (X3 ? X3_TILE_FLOATS : TILE_FLOATS)];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * (X3 ? X3_TILE_FLOATS : TILE_FLOATS)];
   if ((int)blockIdx.x >= wa.gemm_blocks) {
     const int bid = blockIdx.x - wa.gemm_blocks;
     int j = 0;
@@ -495,42 +591,52 @@ __global__ __launch_bounds__(256) void weight_grads_kernel(WeightGradArgs wa) {
   const GemmArgs &p = ga.g[g];
   const int local = blockIdx.x - ga.first[g];
   const int tiles = p.tiles_n * ((p.M + BM - 1) / BM);
-  gemm_tile<1, true, false, MTAM_EPI_ATOMIC>(p, As, Bs, local % tiles, local / tiles);
+  gemm_tile<1, true, false, MTAM_EPI_ATOMIC, X3>(p, As, Bs, local % tiles, local / tiles);
 }
 
+template <bool X3>
 __global__ __launch_bounds__(256) void gemm_tn_atomic_grouped_kernel(GroupArgs ga) {
-  __shared__ __attribute__((aligned(16))) float As[2 * TILE_FLOATS];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float As[2 * (X3 ? X3_TILE_FLOATS : TILE_FLOATS)];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * (X3 ? X3_TILE_FLOATS : TILE_FLOATS)];
   int g = 0;
   while (g + 1 < ga.n && (int)blockIdx.x >= ga.first[g + 1]) ++g;
   const GemmArgs &p = ga.g[g];
   const int local = blockIdx.x - ga.first[g];
   const int tiles = p.tiles_n * ((p.M + BM - 1) / BM);
-  gemm_tile<1, true, false, MTAM_EPI_ATOMIC>(p, As, Bs, local % tiles, local / tiles);
+  gemm_tile<1, true, false, MTAM_EPI_ATOMIC, X3>(p, As, Bs, local % tiles, local / tiles);
 }
 
-template <int MW, bool TA, bool TB>
+// MTAM_GEMM_SPLIT=0: every product on v_mfma_f32_32x32x2_f32 (read once)
+bool split_enabled() {
+  static const bool on = [] {
+    const char *e = getenv("MTAM_GEMM_SPLIT");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+template <int MW, bool TA, bool TB, bool X3>
 void launch_epi(int epi, dim3 grid, hipStream_t s, const GemmArgs &a) {
   switch (epi) {
-    case MTAM_EPI_STORE: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_STORE>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_BIAS: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_BIAS>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_BIAS_RELU>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_RELU_ADD: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_RELU_ADD>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ACCUM>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_ACCUM_MASK: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ACCUM_MASK>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_ACCUM2_MASK: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ACCUM2_MASK>), grid, dim3(256), 0, s, a); break;
-    case MTAM_EPI_STORE_SQ: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_STORE_SQ>), grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ATOMIC>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_STORE: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_STORE, X3>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_BIAS: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_BIAS, X3>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_BIAS_RELU, X3>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_RELU_ADD: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_RELU_ADD, X3>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ACCUM, X3>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_ACCUM_MASK: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ACCUM_MASK, X3>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_ACCUM2_MASK: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ACCUM2_MASK, X3>), grid, dim3(256), 0, s, a); break;
+    case MTAM_EPI_STORE_SQ: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_STORE_SQ, X3>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((gemm_f32_kernel<MW, TA, TB, MTAM_EPI_ATOMIC, X3>), grid, dim3(256), 0, s, a); break;
   }
 }
-template <int MW>
+template <int MW, bool X3>
 void launch_trans(int trans_a, int trans_b, int epi, dim3 grid, hipStream_t s, const GemmArgs &a) {
   if (trans_a) {
-    if (trans_b) launch_epi<MW, true, true>(epi, grid, s, a);
-    else         launch_epi<MW, true, false>(epi, grid, s, a);
+    if (trans_b) launch_epi<MW, true, true, X3>(epi, grid, s, a);
+    else         launch_epi<MW, true, false, X3>(epi, grid, s, a);
   } else {
-    if (trans_b) launch_epi<MW, false, true>(epi, grid, s, a);
-    else         launch_epi<MW, false, false>(epi, grid, s, a);
+    if (trans_b) launch_epi<MW, false, true, X3>(epi, grid, s, a);
+    else         launch_epi<MW, false, false, X3>(epi, grid, s, a);
   }
 }
 
@@ -554,6 +660,9 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float 
                      int split_k, void *stream) {
   MTAM_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: M, N, K must be positive (got %d %d %d)", M, N, K);
   MTAM_CHECK_ARG(A && B && C, "gemm: null operand");
+  const bool x3 = (epilogue & MTAM_GEMM_SPLIT_BF16) != 0 && split_enabled() &&
+                  (epilogue & ~MTAM_GEMM_SPLIT_BF16) != MTAM_EPI_STORE_SQ;      // (STORE_SQ partials are sized for the fp32 tiling)
+  epilogue &= ~MTAM_GEMM_SPLIT_BF16;
   MTAM_CHECK_ARG(epilogue >= MTAM_EPI_STORE && epilogue <= MTAM_EPI_STORE_SQ, "gemm: bad epilogue %d", epilogue);
   if (epilogue == MTAM_EPI_STORE_SQ) MTAM_CHECK_ARG(aux_out != nullptr, "gemm: STORE_SQ needs aux_out for the partial sums");
   MTAM_CHECK_ARG(lda >= (trans_a ? M : K), "gemm: lda %d too small", lda);
@@ -568,7 +677,7 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float 
   int k_chunk = (K + split_k - 1) / split_k;
   k_chunk = ((k_chunk + BK - 1) / BK) * BK;
   split_k = (K + k_chunk - 1) / k_chunk;
-  const bool tall = use_tall_tile(M, N, split_k);
+  const bool tall = !x3 && use_tall_tile(M, N, split_k);
   const long gx = (N + BN - 1) / BN, gy = tall ? (M + 127) / 128 : (M + BM - 1) / BM;
   MTAM_CHECK_ARG(gx * gy <= 0x7fffffffL && split_k <= 65535, "gemm: grid too large");
 
@@ -598,8 +707,9 @@ static int gemm_impl(int trans_a, int trans_b, int M, int N, int K, const float 
   }
   dim3 grid((unsigned)(gx * gy), (unsigned)split_k, 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (tall) launch_trans<2>(trans_a, trans_b, epilogue, grid, s, a);
-  else      launch_trans<1>(trans_a, trans_b, epilogue, grid, s, a);
+  if (tall)    launch_trans<2, false>(trans_a, trans_b, epilogue, grid, s, a);
+  else if (x3) launch_trans<1, true>(trans_a, trans_b, epilogue, grid, s, a);
+  else         launch_trans<1, false>(trans_a, trans_b, epilogue, grid, s, a);
   MTAM_CHECK_LAUNCH("gemm");
   return MTAM_OK;
 }
@@ -646,7 +756,7 @@ extern "C" int mtam_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int
   a.vecC = 0;
   dim3 grid((unsigned)(gx * gy), (unsigned)(batch0 * batch1), 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  launch_trans<1>(trans_a, trans_b, epilogue, grid, s, a);
+  launch_trans<1, false>(trans_a, trans_b, epilogue, grid, s, a);
   MTAM_CHECK_LAUNCH("gemm_batched");
   return MTAM_OK;
 }
@@ -703,7 +813,10 @@ extern "C" int mtam_gemm_tn_atomic_grouped(int n, const MtamGemmDesc *d, void *s
   int blocks = 0;
   const int rc = fill_group(n, d, ga, blocks);
   if (rc) return rc;
-  hipLaunchKernelGGL(gemm_tn_atomic_grouped_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), ga);
+  if (split_enabled())
+    hipLaunchKernelGGL(gemm_tn_atomic_grouped_kernel<true>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), ga);
+  else
+    hipLaunchKernelGGL(gemm_tn_atomic_grouped_kernel<false>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), ga);
   MTAM_CHECK_LAUNCH("gemm_grouped");
   return MTAM_OK;
 }
@@ -717,7 +830,10 @@ extern "C" int mtam_weight_grads(int n_gemm, const MtamGemmDesc *d, int n_colsum
   rc = fill_colsums(n_colsum, jobs, wa.c, cb);
   if (rc) return rc;
   wa.gemm_blocks = gb;
-  hipLaunchKernelGGL(weight_grads_kernel, dim3(gb + cb), dim3(256), 0, static_cast<hipStream_t>(stream), wa);
+  if (split_enabled())
+    hipLaunchKernelGGL(weight_grads_kernel<true>, dim3(gb + cb), dim3(256), 0, static_cast<hipStream_t>(stream), wa);
+  else
+    hipLaunchKernelGGL(weight_grads_kernel<false>, dim3(gb + cb), dim3(256), 0, static_cast<hipStream_t>(stream), wa);
   MTAM_CHECK_LAUNCH("weight_grads");
   return MTAM_OK;
 }

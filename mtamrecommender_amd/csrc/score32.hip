@@ -15,6 +15,7 @@
 // independent accumulator chains per tile: a dependent MFMA issues every ~84 cycles, an independent one
 // every 64).  Evaluation keeps the stored-logits GEMM (its k-ordered fmaf chain is the ranking contract).
 #include "common.h"
+#include "split_bf16.h"
 #include <stdlib.h>
 
 // In-kernel stamps for tools/score_lab.hip (a diagnostic build, -DMTAM_SCORE_STAMPS): timer ticks per segment of a
@@ -334,9 +335,7 @@ __global__ __launch_bounds__(256) void score32_bwd_kernel(BwdArgs p) {
 // against float64); the evaluation path keeps the k-ordered fmaf chain (the top-K contract).
 namespace x3 {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+using namespace split_bf16;
 
 // Which slabs a workgroup takes.  BLOCKED (slabs_per_wg > 0): a contiguous range.  CYCLIC (slabs_per_wg <= 0):
 // slabs c, c + G, c + 2 G, ..: at any moment the grid reads ONE contiguous window of G x 16 KB instead of G streams a
@@ -353,35 +352,6 @@ __device__ __forceinline__ SlabWalk slab_walk(int c, int G, int slabs_per_wg, in
 }
 
 
-__device__ __forceinline__ void split3(float x, __bf16 &a, __bf16 &b, __bf16 &c) {
-  a = (__bf16)x;
-  const float r1 = x - (float)a;
-  b = (__bf16)r1;
-  c = (__bf16)(r1 - (float)b);
-}
-struct Tri {
-  bf16x8 t[3];
-};
-__device__ __forceinline__ Tri split8(const float (&x)[8]) {
-  Tri o;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    __bf16 a, b, c;
-    split3(x[j], a, b, c);
-    o.t[0][j] = a; o.t[1][j] = b; o.t[2][j] = c;
-  }
-  return o;
-}
-// the six products of weight >= 2^-16, smallest first
-__device__ __forceinline__ f32x16 mfma6(const Tri &a, const Tri &b, f32x16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[2], b.t[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[1], b.t[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[1], b.t[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[0], acc, 0, 0, 0);
-  return acc;
-}
 // the wave's 32 batch rows as an operand (row b, k = d = 16 s + 8 h + j), split
 __device__ __forceinline__ void load_pred_rows(Tri (&p1)[8], const float *__restrict__ row, int h) {
 #pragma unroll
@@ -396,20 +366,12 @@ __device__ __forceinline__ void load_pred_rows(Tri (&p1)[8], const float *__rest
 // image serves row reads (ds_read_b128) and transposed reads (ds_read_b64_tr_b16) through a chunk swizzle
 constexpr int E2_IMG = SLAB * 256;       // one of the three images of a 32-row slab
 constexpr int GT2_IMG = BT * 64;         // G^T[b][v]: 128 rows of 32 v
-typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int e_off(int row, int ch) {      // 16-byte chunk ch (0..15) of image row `row`
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 __device__ __forceinline__ int gt_off(int b, int ch) {       // 16-byte chunk ch (0..3) of G^T row b
   return 64 * b + 16 * (ch ^ ((b >> 2) & 3));
-}
-__device__ __forceinline__ bf16x8 lds_tr8(const unsigned char *lo, const unsigned char *hi) {
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(lo));
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(hi));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(bf16x8, v);
 }
 // staged fp32 slab (4 x 16 B per thread of a 256-thread role) -> three swizzled bf16 images
 __device__ __forceinline__ void stage_store_split_tr(const Stage &st, unsigned char *e_img, int tid) {

@@ -35,12 +35,18 @@ def _pi(t):
     return _p(t, torch.int32)
 
 
+GEMM_SPLIT_BF16 = 0x100      # MTAM_GEMM_SPLIT_BF16 (include/mtam_hip.h)
+
+
 def gemm(a, b, c, trans_a=False, trans_b=False, epilogue=EPI_STORE, bias=None, aux_in=None,
-         aux_out=None, split_k=1, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, ld_aux=None):
+         aux_out=None, split_k=1, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, ld_aux=None, split=True):
     """C = op(A) op(B) (+ epilogue).  2-D tensors; leading dimensions default to row lengths.
     Sub-matrix views are expressed with explicit M/N/K/ld* over a base tensor slice
-    obtained by ``tensor.view(-1)[offset:]``."""
+    obtained by ``tensor.view(-1)[offset:]``.  ``split``: products on the bf16 matrix cores from operands split
+    three ways (fp32-equivalent); the evaluation logits pass ``split=False`` (k-ordered fp32 fmaf chain)."""
     lib = _lib.load()
+    if split:
+        epilogue |= GEMM_SPLIT_BF16
     if lda is None:
         lda = a.shape[-1]
     if ldb is None:
@@ -60,9 +66,11 @@ def gemm(a, b, c, trans_a=False, trans_b=False, epilogue=EPI_STORE, bias=None, a
     _lib.check(rc, "mtam_gemm_f32")
 
 
-def gemm_dual(a, b, a2, b2, c, trans_b=True, epilogue=EPI_STORE, bias=None, aux_in=None, aux_out=None):
+def gemm_dual(a, b, a2, b2, c, trans_b=True, epilogue=EPI_STORE, bias=None, aux_in=None, aux_out=None, split=True):
     """C = A op(B) + A2 op(B2) (+ epilogue); A [M,K], A2 [M,K2] row-major, B/B2 as in ``gemm``."""
     lib = _lib.load()
+    if split:
+        epilogue |= GEMM_SPLIT_BF16
     M, K, K2 = a.shape[0], a.shape[1], a2.shape[1]
     N = b.shape[0] if trans_b else b.shape[1]
     ld_aux = aux_in.shape[-1] if aux_in is not None else 0

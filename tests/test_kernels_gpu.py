@@ -35,14 +35,15 @@ def ops(hip_lib):
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(64, 64, 32), (100, 70, 45), (6400, 128, 256), (130, 384, 129)])
-def test_gemm_store(ops, ta, tb, M, N, K):
+@pytest.mark.parametrize("split", [False, True])          # fp32 MFMA chain / six bf16 products of the split operands
+def test_gemm_store(ops, ta, tb, M, N, K, split):
     rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
     A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
     Bm = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
     ref = (A.T if ta else A).astype(np.float64) @ (Bm.T if tb else Bm).astype(np.float64)
     C = torch.full((M, N), 7.0, device="cuda")
-    ops.gemm(dev(A), dev(Bm), C, trans_a=bool(ta), trans_b=bool(tb))
-    assert rel_err(C.cpu().numpy(), ref) < 2e-6     # fp32 fma chain over K <= 256
+    ops.gemm(dev(A), dev(Bm), C, trans_a=bool(ta), trans_b=bool(tb), split=split)
+    assert rel_err(C.cpu().numpy(), ref) < 2e-6     # fp32 fma chain over K <= 256; the split products are no worse
 
 
 def test_gemm_is_ordered_fma_chain(ops):
@@ -53,13 +54,16 @@ def test_gemm_is_ordered_fma_chain(ops):
     A = rng.standard_normal((M, K)).astype(np.float32)
     Bt = rng.standard_normal((N, K)).astype(np.float32)
     C = torch.zeros((M, N), device="cuda")
-    ops.gemm(dev(A), dev(Bt), C, trans_b=True)
+    ops.gemm(dev(A), dev(Bt), C, trans_b=True, split=False)
     import oracle.c_oracle as co
     ref = co.score_fma(A, Bt)
     assert np.array_equal(C.cpu().numpy(), ref)
 
 
-def test_gemm_epilogues(ops):
+@pytest.mark.parametrize("split", [False, True])
+def test_gemm_epilogues(ops, split):
+    import functools
+    ops_gemm = functools.partial(ops.gemm, split=split)
     rng = np.random.default_rng(11)
     M, N, K = 150, 200, 96
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -71,37 +75,38 @@ def test_gemm_epilogues(ops):
     tol = 2e-6
 
     C = torch.zeros((M, N), device="cuda")
-    ops.gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_BIAS, bias=dev(bias))
+    ops_gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_BIAS, bias=dev(bias))
     assert rel_err(C.cpu().numpy(), acc + bias) < tol
-    ops.gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_BIAS_RELU, bias=dev(bias))
+    ops_gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_BIAS_RELU, bias=dev(bias))
     assert rel_err(C.cpu().numpy(), np.maximum(acc + bias, 0)) < tol
     aux_out = torch.zeros((M, N), device="cuda")
-    ops.gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_RELU_ADD, aux_in=dev(aux), aux_out=aux_out)
+    ops_gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_RELU_ADD, aux_in=dev(aux), aux_out=aux_out)
     assert rel_err(aux_out.cpu().numpy(), np.maximum(acc, 0)) < tol
     assert rel_err(C.cpu().numpy(), np.maximum(acc, 0) + aux) < tol
     C = dev(c0).clone()
-    ops.gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_ACCUM)
+    ops_gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_ACCUM)
     assert rel_err(C.cpu().numpy(), c0 + acc) < tol
     C = dev(c0).clone()
-    ops.gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_ACCUM_MASK, aux_in=dev(aux), aux_out=aux_out)
+    ops_gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_ACCUM_MASK, aux_in=dev(aux), aux_out=aux_out)
     assert rel_err(C.cpu().numpy(), c0 + acc) < tol
     assert rel_err(aux_out.cpu().numpy(), np.where(aux > 0, c0 + acc, 0)) < tol
     add2 = rng.standard_normal((M, N)).astype(np.float32)
     C = dev(c0).clone()
-    ops.gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_ACCUM2_MASK, bias=dev(add2), aux_in=dev(aux), aux_out=aux_out)
+    ops_gemm(dev(A), dev(Bm), C, epilogue=ops.EPI_ACCUM2_MASK, bias=dev(add2), aux_in=dev(aux), aux_out=aux_out)
     assert rel_err(C.cpu().numpy(), c0 + acc + add2) < tol
     assert rel_err(aux_out.cpu().numpy(), np.where(aux > 0, c0 + acc + add2, 0)) < tol
 
 
+@pytest.mark.parametrize("x3", [False, True])
 @pytest.mark.parametrize("split", [1, 4, 25])
-def test_gemm_split_k_atomic(ops, split):
+def test_gemm_split_k_atomic(ops, split, x3):
     rng = np.random.default_rng(split)
     K, M, N = 1850, 128, 384          # K = B*L of a short final batch (37 x 50)
     A = rng.standard_normal((K, M)).astype(np.float32)
     Bm = rng.standard_normal((K, N)).astype(np.float32)
     c0 = rng.standard_normal((M, N)).astype(np.float32)
     C = dev(c0).clone()
-    ops.gemm(dev(A), dev(Bm), C, trans_a=True, epilogue=ops.EPI_ATOMIC, split_k=split)
+    ops.gemm(dev(A), dev(Bm), C, trans_a=True, epilogue=ops.EPI_ATOMIC, split_k=split, split=x3)
     ref = c0 + A.T.astype(np.float64) @ Bm.astype(np.float64)
     assert rel_err(C.cpu().numpy(), ref) < 5e-6
 
@@ -755,7 +760,7 @@ def test_gemm_store_sq_epilogue(ops):
     assert rel_err(c.cpu().numpy(), ref) < 1e-5
     assert abs(float(part.double().sum()) - float((ref ** 2).sum())) / float((ref ** 2).sum()) < 1e-5
     c2 = torch.zeros((M, N), device="cuda")
-    ops.gemm(dev(a), dev(b), c2, trans_a=True)
+    ops.gemm(dev(a), dev(b), c2, trans_a=True, split=False)      # (STORE_SQ always takes the fp32 chain)
     assert torch.equal(c, c2)
 
 
