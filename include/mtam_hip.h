@@ -414,13 +414,20 @@ int mtam_score16_bwd(const uint16_t *E16, const uint16_t *P16, const float *lse,
 int mtam_score16_logits(const uint16_t *E16, const uint16_t *P16, int B, int V, float *logits, long ld,
                         void *stream);
 
-/* ------------------------------------------- fp32 scoring without logits (launch-bound catalogs)
- * The pair above with fp32 operands on v_mfma_f32_32x32x2_f32: E [V, 128] and pred [B, 128] as they are
- * (no copies, no padding).  Meant for catalogs where the step is bound by launches, not bytes (ml-1m):
- * it replaces the logits GEMM, mtam_softmax_ce and the two scoring-gradient GEMMs of a training step.
+/* ------------------------------------------- fp32 scoring without logits (every catalog size)
+ * The pair above with fp32 operands: E [V, 128] and pred [B, 128] as they are (no copies, no padding).  It replaces
+ * the logits GEMM, mtam_softmax_ce and the two scoring-gradient GEMMs of a training step
+ * (Model/base_model.py:300-328, 290-297); no [B, V] buffer exists.  Two forms of the same two passes:
+ *   split-bf16 (default): every product as six v_mfma_f32_32x32x16_bf16 terms of operands split three ways
+ *                         (fp32-equivalent, csrc/split_bf16.h); the backward runs in three wave roles with transposed
+ *                         LDS reads (csrc/score32.hip);
+ *   native fp32:          v_mfma_f32_32x32x2_f32 (each score a k-ordered fmaf chain).
+ * Catalogs of at least min_rows rows take the split form (default 1 = always; 0 = never; MTAM_SCORE32_SPLIT_MIN_ROWS
+ * at load, the setter at run time).  The buffer sizes below depend on the form: set it before sizing.
  * Evaluation keeps the stored-logits GEMM (its k-ordered fmaf chain is the ranking contract of mtam_topk).
  *   partial: mtam_score32_partials(B, V) floats; sq_partial: mtam_score32_sq_partials(V) floats or NULL;
  *   d_pred is accumulated (the caller zeroes it), dE [V, 128] is stored. */
+void mtam_score32_set_split_min_rows(long min_rows);
 int mtam_score32_partials(int B, int V);
 int mtam_score32_sq_partials(int V);
 int mtam_score32_lse(const float *E, const float *pred, const int32_t *target, int B, int V, float *partial,

@@ -250,18 +250,13 @@ class TimeAwarePath(object):
         self.nb_dense = ops.sqnorm_blocks(self.n_dense)
         # the dense item gradient's squared norm comes out of its GEMM's epilogue (one partial per wave)
         self.nb_item = ops.gemm_sq_partials(self.item_rows, D)
-        # fp32 training on a small catalog is bound by launches, not bytes: score without stored logits there
-        # (csrc/score32.hip: three launches instead of four, no [B, V] round trips).  Measured per step at
-        # B=128: 3,709 rows 0.3012 vs 0.3049 ms, 8,003 rows 0.3128 vs 0.3095, 30,003 rows 0.379 vs 0.352 --
-        # every 32-row slab flushes a [128, 128] share of d_pred by atomics, which stops paying beyond a few
-        # thousand rows.  MTAM_FUSED_SCORE_MAX_ROWS overrides the limit (0 = never)
-        # Large catalogs (>= MTAM_FUSED_SCORE_MIN_LARGE_ROWS, default 65,536) never materialise [B, V] either
-        # (SURVEY.md K9): the same two entry points, each workgroup owning a contiguous range of slabs with its
-        # share of d_pred in accumulator registers for the whole range (one flush of <= 512 x 64 KB); from
-        # 65,536 rows on they run the fp32 products as six bf16 MFMA terms per product (csrc/score32.hip, x3)
-        self.logits_free32 = score_dtype == "f32" and \
-            (self.item_rows <= int(os.environ.get("MTAM_FUSED_SCORE_MAX_ROWS", "4096")) or
-             self.item_rows >= int(os.environ.get("MTAM_FUSED_SCORE_MIN_LARGE_ROWS", "65536")))
+        # fp32 TRAINING scores the catalog without stored logits at every size (csrc/score32.hip: the log-sum-exp pass,
+        # then one pass that recomputes a slab's scores and forms both scoring gradients; SURVEY.md K9 asks for it
+        # from 1 M rows).  Per step at B=128 against logits GEMM + softmax-CE + two gradient GEMMs: 3,709 rows 0.2722
+        # vs 0.2740 ms, 8,000 rows 0.2812 vs 0.2830, 30,000 rows 0.3235 vs 0.3275, 60,000 rows 0.3669 vs 0.3828.
+        # MTAM_TRAIN_STORED_LOGITS=1 keeps the four-launch form (evaluation always scores through the GEMM: its
+        # k-ordered fmaf chain is the ranking contract)
+        self.logits_free32 = score_dtype == "f32" and os.environ.get("MTAM_TRAIN_STORED_LOGITS", "0") != "1"
         if self.logits_free32:
             self.nb_item = ops.score32_sq_partials(self.item_rows)
         self.item16 = None

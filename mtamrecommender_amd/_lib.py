@@ -84,6 +84,7 @@ SIGNATURES = {
     "mtam_score16_lse": (c_int, [P, P, P, c_int, c_int, P, P, P, P]),
     "mtam_score16_bwd": (c_int, [P, P, P, P, c_int, c_int, c_float, P, P, P, P]),
     "mtam_seq_chain_fwd": (c_int, [P, P, P, c_int, P, P, c_int, P, P, c_int, P, P, P, P, P]),
+    "mtam_score32_set_split_min_rows": (None, [ctypes.c_long]),
     "mtam_score32_partials": (c_int, [c_int, c_int]),
     "mtam_score32_sq_partials": (c_int, [c_int]),
     "mtam_score32_lse": (c_int, [P, P, P, c_int, c_int, P, P, P, P]),

@@ -714,14 +714,16 @@ __global__ __launch_bounds__(768) void bwd_tr3_kernel(BwdArgs p) {
 
 }  // namespace x3
 
-// which form a catalog of V rows is scored with: the split-bf16 kernels from MTAM_SCORE32_SPLIT_MIN_ROWS rows on
-// (default 65,536; 0 = never).  Below that a step is bound by launches, not by the matrix rate.
+// which form a catalog of V rows is scored with: the split-bf16 kernels from g_split_min_rows rows on (default 1:
+// always -- 0.2722 against 0.2740 ms per step at 3,709 rows, and the native pair falls behind from there; 0 = never).
+// MTAM_SCORE32_SPLIT_MIN_ROWS sets it at load, mtam_score32_set_split_min_rows() at run time (the tests run both forms).
+long g_split_min_rows = -1;
 bool use_split(int V) {
-  static const long min_rows = [] {
+  if (g_split_min_rows < 0) {
     const char *e = getenv("MTAM_SCORE32_SPLIT_MIN_ROWS");
-    return e ? atol(e) : 65536L;
-  }();
-  return min_rows > 0 && V >= min_rows;
+    g_split_min_rows = e ? atol(e) : 1L;
+  }
+  return g_split_min_rows > 0 && V >= g_split_min_rows;
 }
 int slabs_of(int V) { return (V + SLAB - 1) / SLAB; }
 // Workgroups per batch tile: each owns a contiguous range of slabs and flushes its [128, 128] share of d_pred
@@ -755,6 +757,8 @@ int slabs_per_wg_of(int V) { return cyclic(V) ? 0 : (slabs_of(V) + chunks_of(V) 
 int grid_of(int V) { return cyclic(V) ? chunks_of(V) : (slabs_of(V) + slabs_per_wg_of(V) - 1) / slabs_per_wg_of(V); }
 
 }  // namespace
+
+extern "C" void mtam_score32_set_split_min_rows(long min_rows) { g_split_min_rows = min_rows < 0 ? 0 : min_rows; }
 
 extern "C" int mtam_score32_partials(int B, int V) { return B * lse_grid_of(V) * 2; }
 extern "C" int mtam_score32_sq_partials(int V) { return grid_of(V) * 4; }

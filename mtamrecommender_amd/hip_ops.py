@@ -395,6 +395,11 @@ def seq_chain_gather_fwd(item_table, cat_table, pos_table, user_table, item_ids,
     _lib.check(rc, "mtam_seq_chain_gather_fwd")
 
 
+def score32_set_split_min_rows(min_rows):
+    """Catalogs of at least ``min_rows`` rows are scored by the split-bf16 kernels (0 = never); sizes follow."""
+    _lib.load().mtam_score32_set_split_min_rows(int(min_rows))
+
+
 def score32_partials(B, V):
     return _lib.load().mtam_score32_partials(B, V)
 

@@ -881,11 +881,22 @@ def test_gather_reads_item_rows_from_the_bf16_copy(ops):
 
 @pytest.mark.parametrize("B,V", [(128, 3709), (100, 1000), (37, 63), (256, 7001), (130, 70007), (128, 200003),
                                  (61, 65536)])
-def test_score32_lse_and_backward(ops, B, V):
+@pytest.mark.parametrize("form", ["split", "native"])
+def test_score32_lse_and_backward(ops, B, V, form):
     """csrc/score32.hip (fp32 logits-free scoring) against float64 products of the same fp32 operands:
-    fp32 products and sums, so 2e-5 of the largest entry (G itself is formed in fp32 here).  From 65,536 rows on
-    the entry points run every fp32 product as six bf16 MFMA terms (three-way operand splits): the same
+    fp32 products and sums, so 2e-5 of the largest entry (G itself is formed in fp32 here).  Both forms: native
+    fp32 MFMA, and (the default) every fp32 product as six bf16 MFMA terms of three-way operand splits: the same
     tolerances hold, and the tighter ones below show that nothing of fp32's accuracy is given up."""
+    if form == "native" and V > 100000:
+        pytest.skip("the native pair is not used at this size")
+    ops.score32_set_split_min_rows(1 if form == "split" else 0)
+    try:
+        _score32_case(ops, B, V, form)
+    finally:
+        ops.score32_set_split_min_rows(1)
+
+
+def _score32_case(ops, B, V, form):
     rng = np.random.default_rng(B * 3 + V)
     E = dev((rng.standard_normal((V, D)) * 0.2).astype(np.float32))
     P = dev(rng.standard_normal((B, D)).astype(np.float32))
@@ -913,7 +924,7 @@ def test_score32_lse_and_backward(ops, B, V):
     assert float((d_pred.double() - ref_dpred).abs().max()) < 2e-5 * float(ref_dpred.abs().max())
     assert float((dE.double() - ref_dE).abs().max()) < 2e-5 * float(ref_dE.abs().max())
     assert abs(float(sq.double().sum()) - float((dE.double() ** 2).sum())) < 1e-5 * float((dE.double() ** 2).sum())
-    if V >= 65536:
+    if form == "split" and V >= 1000:
         # fp32-level accuracy of the split products: as close to float64 as a native fp32 matmul of the operands is
         nat_lse = torch.logsumexp(P @ E.T, 1).double()
         assert float((lse.double() - ref_lse).abs().max()) <= 2.0 * float((nat_lse - ref_lse).abs().max()) + 1e-6
