@@ -9,6 +9,7 @@ Embedding.make_feed_dic_new and TF's gather do, Embedding/Behavior_embedding_tim
 runs in C++ on a worker thread one batch ahead of the device.
 """
 import ctypes
+import queue
 import threading
 from collections import deque
 
@@ -215,7 +216,9 @@ class NativeDataInput(object):
         self.epoch_size = (n + self.batch_size - 1) // self.batch_size
         self.i = 0
         self.prefetch = prefetch
-        self._pending = None
+        self._pending = False
+        self._worker = None
+        self._ahead = None
         # Pinned arenas are allocated HERE, on the caller's thread: the worker thread must not make HIP
         # calls (hipHostMalloc while the main thread captures a hipGraph invalidates the capture).
         sizes = {min(self.batch_size, n), n % self.batch_size}
@@ -239,32 +242,60 @@ class NativeDataInput(object):
         rank, world = self.shard
         return g[(len(g) * rank) // world:(len(g) * (rank + 1)) // world]
 
-    def _start(self, i):
-        box = {}
-
-        def work():
+    # One worker thread per iterator, fed batch numbers through a queue (a thread per batch cost the consumer
+    # ~90 us a step: creation plus the start handshake).  It packs exactly one batch ahead of the consumer -- the
+    # pool's three arenas are the batch in use, the one packed ahead and the one the previous H2D copy may still read.
+    def _work(self):
+        while True:
+            i = self._req.get()
+            if i is None:
+                return
             try:
-                box["batch"] = self.packer.pack(self.rs, self._slice(i), consumer=self.consumer)
+                self._res.put(("ok", self.packer.pack(self.rs, self._slice(i), consumer=self.consumer)))
             except Exception as e:                     # re-raised on the consumer side
-                box["error"] = e
-        t = threading.Thread(target=work, daemon=True)
-        t.start()
-        return t, box
+                self._res.put(("error", e))
+
+    def _request(self, i):
+        if self._worker is None:
+            self._req, self._res = queue.Queue(), queue.Queue()
+            self._worker = threading.Thread(target=self._work, daemon=True)
+            self._worker.start()
+        self._req.put(i)
+
+    def peek_prefetched(self):
+        """The batch packed ahead (waits for it; None when there is none).  It stays the next batch of the iterator."""
+        if self._pending and self._ahead is None:
+            self._ahead = self._res.get()
+        return self._ahead[1] if self._ahead is not None and self._ahead[0] == "ok" else None
+
+    def close(self):
+        if self._worker is not None:
+            self._req.put(None)
+            self._worker = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __next__(self):
         if self.i == self.epoch_size:
+            self.close()
             raise StopIteration
         if not self.prefetch:
             batch = self.packer.pack(self.rs, self._slice(self.i), consumer=self.consumer)
         else:
-            if self._pending is None:
-                self._pending = self._start(self.i)
-            t, box = self._pending
-            t.join()
-            self._pending = self._start(self.i + 1) if self.i + 1 < self.epoch_size else None
-            if "error" in box:
-                raise box["error"]
-            batch = box["batch"]
+            if not self._pending:
+                self._request(self.i)
+            kind, batch = self._ahead if self._ahead is not None else self._res.get()
+            self._ahead = None
+            self._pending = self.i + 1 < self.epoch_size
+            if self._pending:
+                self._request(self.i + 1)
+            if kind == "error":
+                self.close()
+                raise batch
         batch.global_size = len(self._global_slice(self.i))
         self.i += 1
         return self.i, batch

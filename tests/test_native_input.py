@@ -142,8 +142,7 @@ def test_eval_between_two_train_batches_leaves_the_prefetched_train_batch_alone(
     packer = BatchPacker(12, emb)
     train = NativeDataInput(rs, 8, packer, consumer="train")
     step, first = next(train)                       # batch 2 is now being prefetched into the train pool
-    train._pending[0].join()
-    pending = train._pending[1]["batch"]
+    pending = train.peek_prefetched()
     snapshot = pending.arena.clone()
     seen = 0
     for _, test_batch in NativeDataInput(rs, 8, packer, index=np.arange(63, -1, -1), consumer="eval"):
