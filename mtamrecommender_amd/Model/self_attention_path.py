@@ -94,7 +94,7 @@ class SelfAttentionPath(TimeAwarePath):
         fd, T, G = bt.feed, self.tables, self.grads
         gseg = lambda name: self.layout.view(G, name)
         part = bt.norm_partial
-        sr = max(1, min(16, R // 256))
+        sr = max(1, min(int(os.environ.get("MTAM_WGRAD_SPLIT", "16")), R // 256))
         self.score_backward(bt)
         ops.layer_norm_bwd(bt.d_pred, self.seg("head/ln")[1], bt.ln_save, B, bt.d_long, gseg("head/ln"))
         d_out, d_in = bt.d_a, bt.d_b

@@ -466,7 +466,9 @@ class TimeAwarePath(object):
         fd, T, G, cfg = bt.feed, self.tables, self.grads, self.cfg
         gseg = lambda name: self.layout.view(G, name)
         part = bt.norm_partial
-        sr = max(1, min(16, R // 256))
+        # split-K slices of the grouped weight-gradient launch: 12 at 6,400 rows = 480 workgroups, one resident wave of
+        # them; measured per step 8: 0.2748, 10: 0.2697, 12: 0.2685, 14: 0.2708, 16: 0.2715, 24: 0.2779 ms
+        sr = max(1, min(int(os.environ.get("MTAM_WGRAD_SPLIT", "12")), R // 256))
         prob = lambda A, lda, Bm, ldb, name, M, N, K, s: dict(A=A, lda=lda, B=Bm, ldb=ldb, C=gseg(name),
                                                               ldc=N, M=M, N=N, K=K, split_k=s)
         self.score_backward(bt)          # d_pred -> head LN -> decoder blocks (last to first)
