@@ -121,6 +121,10 @@ class _Batch(object):
             self.s16_partial = f(ops.score16_partials(B, V))
         self.ce_partial = torch.zeros(ops.softmax_ce_partials(B, V) + 4, dtype=torch.float32, device=dev)
         self.l2_partial = f(ops.emb_gather_partials(B, L))
+        # the fused lookups write 4 sums per 32-row stripe (800 at 6,400 rows, against the gather kernel's 4,832): the
+        # step's last reduction reads one batch of loads instead of three
+        self.l2_fused = self.l2_partial[:ops.seq_chain_gather_partials(B, L)]
+        self.l2_live = self.l2_partial          # (what the last forward wrote: set by it)
         self.loss = f(3)
         # backward
         self.d_dec = [f(B, D) for _ in range(NB + 1)]
@@ -390,11 +394,13 @@ class TimeAwarePath(object):
                                      self.seg("dense4emb/w"),
                                      self.seg("kv/w") if kv_from_x else None, self.seg("kv/b") if kv_from_x else None,
                                      self.seg("gru/wx"), self.seg("gru/bx"), bt.ic if training else None, bt.user,
-                                     bt.l2_partial, bt.zr, bt.x, bt.kv if kv_from_x else None, bt.xproj, clear=clear)
+                                     bt.l2_fused, bt.zr, bt.x, bt.kv if kv_from_x else None, bt.xproj, clear=clear)
+            bt.l2_live = bt.l2_fused          # 4 sums per 32-row stripe: what the loss reduction has to read
         else:
             ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
                                fd["category_list"], fd["position_list"], fd["user_id"], B, L, 1,
                                bt.ic, bt.pos, bt.user, bt.l2_partial, clear=clear, item16=self.item16)
+            bt.l2_live = bt.l2_partial
         if bt.fused_gather:
             pass
         elif chain:
@@ -458,7 +464,7 @@ class TimeAwarePath(object):
         # the loss scalar itself is reduced in the step epilogue (clip_and_apply), off the chain
         ops.softmax_ce_loss(bt.logits_store, bt.ld_logits, bt.feed["target_item_id"], B, V, 1.0 / gb, bt.lse, bt.ce,
                             bt.logits_store,
-                            bt.ce_partial, bt.l2_partial, bt.l2_partial.numel(), self.reg, 1.0 / gb, None)
+                            bt.ce_partial, bt.l2_live, bt.l2_live.numel(), self.reg, 1.0 / gb, None)
 
     # ---------------------------------------------------------------- backward
     def backward(self, bt):
@@ -588,7 +594,7 @@ class TimeAwarePath(object):
             n = ops.sqnorm_blocks(self.n_total)
         gb = self.gb(bt)
         ops.sqnorm_clip_scale(self.flat_g, n_g, part, 0, n, self.clip, self.scale, bt.feed["lr"],
-                              self.adam_state, self.ticket, bt.l2_partial, bt.l2_partial.numel(), bt.ce, bt.B,
+                              self.adam_state, self.ticket, bt.l2_live, bt.l2_live.numel(), bt.ce, bt.B,
                               self.reg, 1.0 / gb, None if self.loss_in_tail else bt.loss)
         if self.optimizer == "adam" and self.item16 is not None:
             # the bf16 scoring copy of the item table is refreshed by the same launch

@@ -66,7 +66,7 @@ def attach(path, world_size, group=None, force=False, shard_items=None):
         bt.loss = path.loss_tail[:3]
 
     def exchange(p, bt):
-        ops.loss_reduce(bt.l2_partial, bt.l2_partial.numel(), bt.ce, bt.B, p.reg, 1.0 / p.gb(bt), p.loss_tail)
+        ops.loss_reduce(bt.l2_live, bt.l2_live.numel(), bt.ce, bt.B, p.reg, 1.0 / p.gb(bt), p.loss_tail)
         allreduce_gradients([p.flat_g[:p.n_items_end + 4]], group)
 
     path.allreduce_fn = exchange
@@ -91,7 +91,7 @@ class HipStepKernels(object):
         self.ops.clip_scale_sq(sq_total, 1, clip, scale, lr, adam_state)
 
     def loss(self, bt, reg, ce_scale):
-        self.ops.loss_reduce(bt.l2_partial, bt.l2_partial.numel(), bt.ce, bt.B, reg, ce_scale, bt.loss)
+        self.ops.loss_reduce(bt.l2_live, bt.l2_live.numel(), bt.ce, bt.B, reg, ce_scale, bt.loss)
 
     def adam(self, p, m, v, g, scale, hyper, sparse_begin):
         self.ops.adam(p, m, v, g, g.numel(), scale, hyper, sparse_begin)
