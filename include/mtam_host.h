@@ -15,6 +15,7 @@
  */
 #ifndef MTAM_HOST_H
 #define MTAM_HOST_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -64,6 +65,10 @@ int mtam_pack_batch(const MtamRecordSet *rs, const int64_t *index, int B, int L,
 /* Fisher-Yates permutation of 0 .. n-1 from a 64-bit seed (splitmix64); the trainer reshuffles the
  * training set every epoch (train_process.py:317). */
 void mtam_shuffle_index(int64_t *index, long n, uint64_t seed);
+
+/* CRC-32C (Castagnoli) of data[0 .. n), continuing from `crc` (0 to start): the checksum TensorFlow's checkpoint
+ * bundle files carry (tensorflow/core/lib/hash/crc32c.h; mtamrecommender_amd/util/tf_bundle.py). */
+uint32_t mtam_crc32c(const void *data, size_t n, uint32_t crc);
 
 int mtam_host_version(void);
 

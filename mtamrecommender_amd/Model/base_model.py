@@ -133,6 +133,12 @@ class base_model(object):
     def restore(self, sess, path, variable_list=None, graph_path=None):
         files = sorted(glob.glob(os.path.join(path, "model.ckpt-*.pt")), key=os.path.getmtime)
         if not files:
+            from ..util import tf_bundle
+            if variable_list is None and os.path.isdir(path) and tf_bundle.latest_checkpoint(path):
+                # a directory the REFERENCE saved into: its TensorFlow bundle, read without TensorFlow
+                prefix = self.import_tf_checkpoint(path)
+                self.logger.info('model restored from the TensorFlow checkpoint %s' % prefix)
+                return
             raise FileNotFoundError("no checkpoint under %s" % path)
         state = torch.load(files[-1], weights_only=True)
         p = self.path
@@ -149,12 +155,10 @@ class base_model(object):
         self.logger.info('model restored from %s' % path)
 
     # ------------------------------------------------- TF-named interchange
-    def export_tf_npz(self, file_path):
+    def tf_named_arrays(self):
         """Every variable a TF 1.14 ``tf.train.Saver`` would hold for this graph, keyed by its TF name
         (SURVEY.md App B): trainable variables, the never-updated ones, and Adam's slots
-        ``<name>/Adam`` (m), ``<name>/Adam_1`` (v), ``beta1_power``, ``beta2_power``.  The other
-        direction of ``import_tf_npz``; a reference checkpoint becomes such a file with
-        ``{n: r.get_tensor(n) for n in r.get_variable_to_shape_map()}`` on a machine that has TF."""
+        ``<name>/Adam`` (m), ``<name>/Adam_1`` (v), ``beta1_power``, ``beta2_power``."""
         p = self.path
         out = dict(self.get_variables())
         if p.optimizer == "adam":
@@ -166,21 +170,53 @@ class base_model(object):
                 out["embedding_layer/%s/Adam_1" % k] = p.tv[k].detach().cpu().numpy()
             st = p.adam_state.cpu().numpy()
             out["beta1_power"], out["beta2_power"] = np.float32(st[4]), np.float32(st[5])
+        return out
+
+    def export_tf_npz(self, file_path):
+        """``tf_named_arrays()`` as one .npz file.  The other direction of ``import_tf_npz``; a reference checkpoint
+        becomes such a file with ``{n: r.get_tensor(n) for n in r.get_variable_to_shape_map()}`` on a machine that
+        has TF -- or is read directly by ``import_tf_checkpoint``."""
+        out = self.tf_named_arrays()
         np.savez(file_path, **{k.replace("/", "__"): v for k, v in out.items()})
         return sorted(out)
+
+    def export_tf_checkpoint(self, prefix):
+        """``tf_named_arrays()`` as a TensorFlow checkpoint bundle (``<prefix>.index``, ``.data-00000-of-00001`` and
+        the directory's ``checkpoint`` state file): what ``tf.train.Saver().save`` leaves (Model/base_model.py:331-337
+        of the reference), written by ``util/tf_bundle.py`` without TensorFlow."""
+        from ..util import tf_bundle
+        names = tf_bundle.write_bundle(prefix, {k: np.asarray(v) for k, v in self.tf_named_arrays().items()})
+        tf_bundle.write_checkpoint_state(os.path.dirname(os.path.abspath(prefix)), prefix)
+        return names
 
     def import_tf_npz(self, file_path):
         """Load variables (and, when present, Adam slots) from an ``export_tf_npz``-style file.  Keys may
         carry TF's ``:0`` suffix; shapes are checked; a trainable variable missing from the file raises."""
-        p = self.path
         raw = np.load(file_path, allow_pickle=False)
-        arrays = {k.replace("__", "/").split(":")[0]: raw[k] for k in raw.files}
+        self._import_tf_arrays({k.replace("__", "/").split(":")[0]: raw[k] for k in raw.files}, file_path)
+
+    def import_tf_checkpoint(self, prefix_or_dir):
+        """Load a TensorFlow checkpoint bundle -- a reference ``model.ckpt-<step>`` prefix, or a directory holding a
+        ``checkpoint`` state file (``tf.train.latest_checkpoint``) -- read by ``util/tf_bundle.py`` without TensorFlow
+        (``saver.restore``, Model/base_model.py:339-343 of the reference).  Variables the model does not have
+        (``global_step``, other optimizers' slots) are ignored."""
+        from ..util import tf_bundle
+        prefix = prefix_or_dir
+        if os.path.isdir(prefix_or_dir):
+            prefix = tf_bundle.latest_checkpoint(prefix_or_dir)
+            if prefix is None:
+                raise FileNotFoundError("no TensorFlow checkpoint bundle under %s" % prefix_or_dir)
+        self._import_tf_arrays(tf_bundle.read_bundle(prefix), prefix)
+        return prefix
+
+    def _import_tf_arrays(self, arrays, origin):
+        p = self.path
         mine = self.get_variables()
         for k, v in mine.items():
             if k not in arrays:
                 if k in self.dead_variables:
                     continue
-                raise KeyError("variable %s missing from %s" % (k, file_path))
+                raise KeyError("variable %s missing from %s" % (k, origin))
             if tuple(arrays[k].shape) != tuple(v.shape):
                 raise ValueError("%s: shape %s in the file, %s in the model" % (k, arrays[k].shape, v.shape))
         self.set_variables({k: arrays[k] for k in mine if k in arrays})

@@ -27,6 +27,7 @@ SIGNATURES = {
     "mtam_records_get": (c_int, [P, c_long, c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "mtam_pack_batch": (c_int, [P, P, c_int, c_int, P, P, c_float, P, c_char_p, c_int]),
     "mtam_shuffle_index": (None, [P, c_long, c_uint64]),
+    "mtam_crc32c": (ctypes.c_uint32, [P, ctypes.c_size_t, ctypes.c_uint32]),
     "mtam_host_version": (c_int, []),
 }
 

@@ -411,6 +411,35 @@ def test_tf_named_npz_round_trip(hip_lib, tmp_path):
     assert abs(la - lb) <= 1e-5 * abs(la)
 
 
+def test_tf_checkpoint_bundle_round_trip(hip_lib, tmp_path):
+    """export_tf_checkpoint / import_tf_checkpoint / restore(): the same state as a TensorFlow checkpoint bundle
+    (index table + data shard + `checkpoint` state file, util/tf_bundle.py); a model pointed at the directory with
+    the reference's restore() call picks it up.  The bundle format itself: tests/test_tf_bundle.py."""
+    from mtamrecommender_amd.util import tf_bundle
+    model_a, FLAGS, records = build(tmp_path, 16, 8, 1, 1)
+    model_b, _, _ = build(tmp_path, 16, 8, 1, 1, seed=9)
+    model_c, _, _ = build(tmp_path, 16, 8, 1, 1, seed=11)
+    model_a.train(model_a.sess, records, 1e-3)
+    ckpt_dir = tmp_path / "tf_ckpt"
+    names = model_a.export_tf_checkpoint(str(ckpt_dir / "model.ckpt-1"))
+    assert "embedding_layer/item/Adam" in names and "beta1_power" in names
+    listed = tf_bundle.list_bundle(str(ckpt_dir / "model.ckpt-1"))
+    assert listed["embedding_layer/item"] == (np.float32, tuple(model_a.get_variables()["embedding_layer/item"].shape))
+    assert listed["beta1_power"] == (np.float32, ())
+    assert model_b.import_tf_checkpoint(str(ckpt_dir)) == str(ckpt_dir / "model.ckpt-1")
+    model_c.restore(model_c.sess, str(ckpt_dir))                  # the reference's call, on a TF-format directory
+    va = model_a.get_variables()
+    sa = model_a.path.optimizer_state()
+    for other in (model_b, model_c):
+        vo, so = other.get_variables(), other.path.optimizer_state()
+        assert all(np.array_equal(va[k], vo[k]) for k in va)
+        assert torch.equal(sa["flat_m"], so["flat_m"]) and torch.equal(sa["flat_v"], so["flat_v"])
+        assert torch.equal(sa["adam_state"][1:6], so["adam_state"][1:6])
+    la, _ = model_a.train(model_a.sess, records, 1e-3)
+    lb, _ = model_b.train(model_b.sess, records, 1e-3)
+    assert abs(la - lb) <= 1e-5 * abs(la)
+
+
 @pytest.mark.parametrize("member", ["MTAM_only_time_aware_RNN", "MTAM_no_time_aware_rnn", "MTAM_via_T_GRU",
                                     "MTAM_via_rnn", "MTAM_with_T_SeqRec", "MTAM_hybird"])
 @pytest.mark.parametrize("B,L,NB,H", [(6, 8, 1, 1), (33, 50, 2, 2)])
