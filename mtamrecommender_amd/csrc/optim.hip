@@ -412,6 +412,16 @@ extern "C" int mtam_sqnorm_clip_scale(const float *g, size_t n, float *partials,
   return MTAM_OK;
 }
 
+// non-temporal accesses once the seven streams exceed the caches (MTAM_ADAM_NT_MIN_BYTES, default 256 MiB of
+// parameters): 5.62 against 5.91 ms on the 10 M-row step (6.4 TB/s over the 35.8 GB)
+static size_t adam_nt_min_bytes() {
+  static const size_t v = [] {
+    const char *e = getenv("MTAM_ADAM_NT_MIN_BYTES");
+    return e ? (size_t)atoll(e) : ((size_t)1 << 28);
+  }();
+  return v;
+}
+
 extern "C" int mtam_adam_block(void) { return NORM_BLOCK; }
 
 extern "C" int mtam_adam(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
@@ -422,13 +432,7 @@ extern "C" int mtam_adam(float *p, float *m, float *v, const float *g, size_t n,
   MTAM_CHECK_ARG(sparse_begin >= n || sparse_begin % NORM_BLOCK == 0,
                  "adam: sparse_begin must be a multiple of %d (or >= n)", NORM_BLOCK);
   dim3 grid(mtam_sqnorm_blocks(n));
-  // non-temporal accesses once the seven streams exceed the caches (MTAM_ADAM_NT_MIN_BYTES, default 256 MiB of
-  // parameters): 5.62 against 5.91 ms on the 10 M-row step (6.4 TB/s over the 35.8 GB)
-  static const size_t nt_min = [] {
-    const char *e = getenv("MTAM_ADAM_NT_MIN_BYTES");
-    return e ? (size_t)atoll(e) : ((size_t)1 << 28);
-  }();
-  if (n * 4 >= nt_min)
+  if (n * 4 >= adam_nt_min_bytes())
     hipLaunchKernelGGL((adam_kernel<false, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n,
                        scale, hyper, sparse_begin, static_cast<uint16_t *>(nullptr), n);
   else
@@ -449,8 +453,12 @@ extern "C" int mtam_adam_bf16copy(float *p, float *m, float *v, const float *g, 
                  "adam_bf16copy: sparse_begin must be a multiple of %d (or >= n)", NORM_BLOCK);
   MTAM_CHECK_ARG(copy_begin <= n && copy_begin % 4 == 0, "adam_bf16copy: copy_begin must be a multiple of 4");
   dim3 grid(mtam_sqnorm_blocks(n));
-  hipLaunchKernelGGL((adam_kernel<true, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n, scale,
-                     hyper, sparse_begin, copy16, copy_begin);
+  if (n * 4 >= adam_nt_min_bytes())
+    hipLaunchKernelGGL((adam_kernel<true, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n,
+                       scale, hyper, sparse_begin, copy16, copy_begin);
+  else
+    hipLaunchKernelGGL((adam_kernel<true, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n,
+                       scale, hyper, sparse_begin, copy16, copy_begin);
   MTAM_CHECK_LAUNCH("adam_bf16copy");
   return MTAM_OK;
 }
