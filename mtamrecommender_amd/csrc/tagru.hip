@@ -31,8 +31,12 @@
 // step, summed per wave of workgroup 0 and written to a buffer of their own.  The product build has none.
 #ifdef MTAM_GRU_STAMPS
 __device__ unsigned long long g_gru_stamps[2][8][8];      // [kernel][wave][segment]
-#define GRU_STAMP_DECL unsigned long long st_last_, st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define GRU_STAMP_START asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last_)::"memory");
+__device__ unsigned long long g_gru_real[2][8][2];        // [kernel][wave]: s_memtime ticks and s_memrealtime ticks (100 MHz) of the loop
+#define GRU_STAMP_DECL unsigned long long st_last_, st_t0_ = 0, st_r0_ = 0, st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define GRU_STAMP_START                                                                \
+  st_r0_ = __builtin_amdgcn_s_memrealtime();                                           \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last_)::"memory");    \
+  st_t0_ = st_last_;
 #define GRU_STAMP(i)                                                                   \
   {                                                                                    \
     unsigned long long t_;                                                             \
@@ -42,14 +46,44 @@ __device__ unsigned long long g_gru_stamps[2][8][8];      // [kernel][wave][segm
     st_acc_[i] += t_ - st_last_;                                                       \
     st_last_ = t_;                                                                     \
   }
-#define GRU_STAMP_DUMP(k)                                                              \
+__device__ unsigned long long g_gru_phase[2][8][8];       // [kernel][wave][phase]: s_memrealtime ticks (10 ns) between phase marks
+__device__ unsigned long long g_gru_wg[2][256][2];        // [kernel][workgroup]: s_memrealtime at its start and end
+__device__ unsigned long long g_gru_span[2][64][2];       // [kernel][launch & 63]: earliest start, latest end over the launch's workgroups
+__device__ unsigned int g_gru_launch[2];                  // launches so far
+#define GRU_PHASE_DECL unsigned long long ph_last_ = __builtin_amdgcn_s_memrealtime(), ph_t0_ = ph_last_, ph_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+  const unsigned int ph_launch_ = __hip_atomic_load(&g_gru_launch[GRU_KERNEL_ID], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#define GRU_PHASE(i)                                                                   \
+  {                                                                                    \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
+    const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                    \
+    ph_acc_[i] += t_ - ph_last_;                                                       \
+    ph_last_ = t_;                                                                     \
+  }
+#define GRU_PHASE_DUMP(k)                                                              \
+  if (threadIdx.x == 0 && blockIdx.x < 256) {                                          \
+    const unsigned long long te_ = __builtin_amdgcn_s_memrealtime();                   \
+    g_gru_wg[k][blockIdx.x][0] = ph_t0_;                                               \
+    g_gru_wg[k][blockIdx.x][1] = te_;                                                  \
+    atomicMin(&g_gru_span[k][ph_launch_ & 63][0], ph_t0_);                             \
+    atomicMax(&g_gru_span[k][ph_launch_ & 63][1], te_);                                \
+    if (blockIdx.x == 0) atomicAdd(&g_gru_launch[k], 1u);                              \
+  }                                                                                    \
   if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                      \
-    for (int i_ = 0; i_ < 8; ++i_) g_gru_stamps[k][threadIdx.x >> 6][i_] = st_acc_[i_];
+    for (int i_ = 0; i_ < 8; ++i_) g_gru_phase[k][threadIdx.x >> 6][i_] = ph_acc_[i_];
+#define GRU_STAMP_DUMP(k)                                                              \
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                    \
+    for (int i_ = 0; i_ < 8; ++i_) g_gru_stamps[k][threadIdx.x >> 6][i_] = st_acc_[i_]; \
+    g_gru_real[k][threadIdx.x >> 6][0] = st_last_ - st_t0_;                            \
+    g_gru_real[k][threadIdx.x >> 6][1] = __builtin_amdgcn_s_memrealtime() - st_r0_;    \
+  }
 #else
 #define GRU_STAMP_DECL
 #define GRU_STAMP_START
 #define GRU_STAMP(i)
 #define GRU_STAMP_DUMP(k)
+#define GRU_PHASE_DECL
+#define GRU_PHASE(i)
+#define GRU_PHASE_DUMP(k)
 #endif
 
 namespace {
@@ -169,6 +203,9 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
   const int steps = min(max(p.seq_len[b] - 1, 0), p.L);
   const size_t row0 = (size_t)b * p.L;
   const bool seqrec = p.ldx == 5 * D;
+#define GRU_KERNEL_ID 0
+  GRU_PHASE_DECL
+#undef GRU_KERNEL_ID
   // tvec == nullptr: the plain tf GRUCell (Model/Modules/gru.py:13-39) -- no time gate, T = 1
   const bool plain = p.tvec == nullptr && !seqrec;
   const int ldx = p.ldx, nsave = seqrec ? 6 : 5;
@@ -214,10 +251,12 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
   const bool owner = kp == 0 || kp == 2;
   float h_own = 0.f;                               // state of unit q (owner lane)
   GRU_STAMP_DECL
+  GRU_PHASE(0)          // weights: global -> LDS -> registers
 
   for (int t0 = 0; t0 < steps; t0 += TCH) {
     const int nch = min(TCH, steps - t0);
     __syncthreads();                               // the previous chunk's write-back has read the stage
+    GRU_PHASE(1)
     // ---- stage the chunk's inputs (all threads, 16-byte loads, pre-scaled).  Loads go out 8 per thread before
     // the first of them is used (clamped index, masked store): inside a run-time-bounded loop they are waited
     // for one round trip at a time -- 8.7 us of fixed cost per launch before this was batched.
@@ -242,6 +281,7 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
         }
       }
     }
+    GRU_PHASE(2)        // x-projection rows staged
     if (!plain && !seqrec) {                                         // A = x kw1 + kb1 ; S = -log2 e (w12 relu(w1 dt + b1) + b12)
       const int j = tid & (D - 1);
       const float kw1 = p.tvec[KW1 * D + j], kb1 = p.tvec[KB1 * D + j], w1 = p.tvec[W1 * D + j],
@@ -266,6 +306,7 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
       }
     }
     __syncthreads();
+    GRU_PHASE(3)        // time-gate inputs staged
 
     GRU_STAMP_START
     for (int s = 0; s < nch; ++s) {
@@ -331,6 +372,7 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
       GRU_STAMP(7)      // barrier 2
     }
 
+    GRU_PHASE(4)        // the recurrent steps
     // ---- write the chunk back: hs rows and the saved r | u | c | T | h_prev (| N) of every step
     for (int i = tid; i < nch * (D / 4); i += 512) {
       const int s = i / (D / 4), c4 = i - s * (D / 4);
@@ -350,9 +392,11 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
       }
     }
     __syncthreads();
+    GRU_PHASE(5)        // write-back
     if (tid < D) carry_s[tid] = stage[(nch - 1) * ST + OFF_H + tid];
   }
   GRU_STAMP_DUMP(0)
+  GRU_PHASE_DUMP(0)
 
   if (owner) p.short_out[(size_t)b * D + q] = (steps > 0) ? h_own : 0.f;
   // dynamic_rnn zero-fills dead steps

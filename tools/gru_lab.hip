@@ -4,6 +4,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMTAM_GRU_STAMPS tools/gru_lab.hip mtamrecommender_amd/csrc/capi.hip -o tools/gru_lab
 #include "../mtamrecommender_amd/csrc/tagru.hip"
 #include <stdlib.h>
+#include <algorithm>
 #include <vector>
 
 int main() {
@@ -50,6 +51,31 @@ int main() {
     hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms_b, e0, e1);
     printf("fwd %.1f us, bwd %.1f us per launch (B=%d, L=%d)\n", ms_f * 20.f, ms_b * 20.f, B, L);
   }
+#ifdef MTAM_GRU_STAMPS
+  {   // 40 forward launches back to back: when the first workgroup of each started and the last one ended
+    static unsigned long long span[2][64][2];
+    for (int i = 0; i < 64; ++i) { span[0][i][0] = span[1][i][0] = ~0ull; span[0][i][1] = span[1][i][1] = 0; }
+    unsigned int zero2[2] = {0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_gru_span), span, sizeof(span));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_gru_launch), zero2, sizeof(zero2));
+    for (int i = 0; i < 40; ++i) mtam_tagru_fwd(xp, x, tl, sl, wg, wc, tv, B, L, hs, sh, save, nullptr);
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(span, HIP_SYMBOL(g_gru_span), sizeof(span));
+    printf("forward, 40 launches back to back: [workgroups alive us | gap to the next launch's first workgroup us]\n ");
+    for (int i = 20; i < 30; ++i)
+      printf(" [%.1f | %.1f]", (span[0][i][1] - span[0][i][0]) * 0.01, (span[0][i + 1][0] - span[0][i][1]) * 0.01);
+    printf("\n");
+  }
+#endif
+  {   // the forward without its saved-activation writes (evaluation's form): 3.3 MB written instead of 19.7
+    for (int i = 0; i < 5; ++i) mtam_tagru_fwd(xp, x, tl, sl, wg, wc, tv, B, L, hs, sh, nullptr, nullptr);
+    hipDeviceSynchronize();
+    float ms_f;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 50; ++i) mtam_tagru_fwd(xp, x, tl, sl, wg, wc, tv, B, L, hs, sh, nullptr, nullptr);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms_f, e0, e1);
+    printf("fwd without the save writes: %.1f us per launch\n", ms_f * 20.f);
+  }
   {   // the launches' fixed part: the same kernels on sequences of length 1 (no recurrent step at all)
     std::vector<int32_t> one(B, 1);
     int32_t *sl1;
@@ -71,6 +97,10 @@ int main() {
     }
   }
 #ifdef MTAM_GRU_STAMPS
+  // (the stamps below are those of the LAST launch: run the full-length pair again after the short-sequence runs)
+  mtam_tagru_fwd(xp, x, tl, sl, wg, wc, tv, B, L, hs, sh, save, nullptr);
+  mtam_tagru_bwd(ds, nullptr, x, tl, sl, wg, wc, tv, save, B, L, dxp, rh, dxt, dtv, nullptr);
+  hipDeviceSynchronize();
   unsigned long long st[2][8][8];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(g_gru_stamps), sizeof(st));
   const char *fn[8] = {"reads+T+gate FMAs", "reduce+sigmoid+LDS write", "barrier 1", "rh reads+cand FMAs+reduce",
@@ -84,6 +114,27 @@ int main() {
     double tot = 0;
     for (int i = 0; i < 8; ++i) tot += st[k][0][i] / 49.0;
     printf("  total (wave 0)               %7.0f cycles per step\n", tot);
+    unsigned long long rl[2][8][2];
+    hipMemcpyFromSymbol(rl, HIP_SYMBOL(g_gru_real), sizeof(rl));
+    printf("  the loop of wave 0: %llu s_memtime ticks in %llu s_memrealtime ticks (100 MHz): shader clock %.0f MHz\n",
+           rl[k][0][0], rl[k][0][1], 100.0 * (double)rl[k][0][0] / (double)rl[k][0][1]);
+  }
+  {
+    unsigned long long ph[2][8][8];
+    hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_gru_phase), sizeof(ph));
+    const char *pn[6] = {"weights -> registers", "(chunk barrier)", "x-projection rows staged", "time-gate inputs staged",
+                         "recurrent steps", "write-back"};
+    printf("forward, workgroup 0, wave 0: microseconds by phase (s_memrealtime)\n");
+    for (int i = 0; i < 6; ++i) printf("  %-28s %6.2f\n", pn[i], ph[0][0][i] * 0.01);
+    static unsigned long long wg[2][256][2];
+    hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_gru_wg), sizeof(wg));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int i = 0; i < B; ++i) { t0 = std::min(t0, wg[0][i][0]); t1 = std::max(t1, wg[0][i][1]); }
+    printf("forward: %d workgroups, first start to last end %.2f us; start offsets (us) of workgroups 0, 16, 32, ..:", B, (t1 - t0) * 0.01);
+    for (int i = 0; i < B; i += 16) printf(" %.1f", (wg[0][i][0] - t0) * 0.01);
+    printf("\n  durations (us) of the same:");
+    for (int i = 0; i < B; i += 16) printf(" %.1f", (wg[0][i][1] - wg[0][i][0]) * 0.01);
+    printf("\n");
   }
 #endif
   return 0;
