@@ -1,19 +1,21 @@
-// fp32 catalog scoring without stored logits, for catalogs small enough that the step is bound by launches
-// rather than bytes (ml-1m: 3,709 rows): the training loss and both scoring gradients of
-// base_model.output (Model/base_model.py:300-328, 290-297) in TWO launches instead of four
-// (logits GEMM, softmax-CE, dE GEMM, d_pred GEMM) and without the [B, V] round trips between them.
+// fp32 catalog scoring without stored logits: the training loss and both scoring gradients of base_model.output
+// (Model/base_model.py:300-328, 290-297) in TWO passes over the item table instead of four launches (logits GEMM,
+// softmax-CE, dE GEMM, d_pred GEMM) and without any [B, V] buffer.
 //
-//   score32_lse   scores of a 32-row catalog slab on v_mfma_f32_32x32x2_f32, per-row running (max, sum-exp)
-//   score32_bwd   recomputes the slab's scores, forms G = (softmax - onehot) * scale in registers, and
-//                 produces dE (stored, with its squared norm) and the workgroup's share of d_pred (atomics)
+//   lse   scores of a 32-row catalog slab, per-row running (max, sum-exp); a finish launch folds the ranges
+//   bwd   recomputes the slab's scores, forms G = (softmax - onehot) * scale in registers, and produces dE (stored,
+//         with its squared norm) and the workgroup's share of d_pred (atomics)
 //
-// Same structure as csrc/score16.hip with fp32 operands: lane l (r = l & 31, h = l >> 5) of the 32x32x2
-// instruction supplies A[row r][k = h] and B[k = h][col r]; k-step s pairs element s (lane half 0) with
-// element s + 64 (lane half 1) of a 128-long contraction, so a lane's resident operand is 64 contiguous
-// floats, and a staged row keeps its two halves one float apart ([64][gap][64][gap], 130 floats): the
-// 64 lanes of a fragment read then hit 64 distinct LDS banks.  fp32 products, fp32 accumulation (two
-// independent accumulator chains per tile: a dependent MFMA issues every ~84 cycles, an independent one
-// every 64).  Evaluation keeps the stored-logits GEMM (its k-ordered fmaf chain is the ranking contract).
+// Two forms behind the same entry points (mtam_score32_set_split_min_rows picks; the split form is the default):
+//   * namespace x3 (second half of this file): every fp32 product as six bf16 MFMA terms of operands split three
+//     ways (csrc/split_bf16.h), operands as swizzled bf16 images in LDS, the backward in three wave roles;
+//   * the native form below, on v_mfma_f32_32x32x2_f32: lane l (r = l & 31, h = l >> 5) supplies A[row r][k = h] and
+//     B[k = h][col r]; k-step s pairs element s (lane half 0) with element s + 64 (lane half 1) of a 128-long
+//     contraction, so a lane's resident operand is 64 contiguous floats, and a staged row keeps its two halves one
+//     float apart ([64][gap][64][gap], 130 floats): the 64 lanes of a fragment read then hit 64 distinct LDS banks.
+//     Two independent accumulator chains per tile (a dependent fp32 MFMA issues every ~84 cycles, an independent one
+//     every 64).
+// Evaluation keeps the stored-logits GEMM (its k-ordered fmaf chain is the ranking contract).
 #include "common.h"
 #include "split_bf16.h"
 #include <stdlib.h>
