@@ -716,6 +716,7 @@ __global__ __launch_bounds__(768) void bwd_tr3_kernel(BwdArgs p) {
 
 }  // namespace x3
 
+
 // which form a catalog of V rows is scored with: the split-bf16 kernels from g_split_min_rows rows on (default 1:
 // always -- 0.2722 against 0.2740 ms per step at 3,709 rows, and the native pair falls behind from there; 0 = never).
 // MTAM_SCORE32_SPLIT_MIN_ROWS sets it at load, mtam_score32_set_split_min_rows() at run time (the tests run both forms).

@@ -41,6 +41,37 @@ __global__ void k(unsigned long long *out, int iters, float *sink) {
   if ((threadIdx.x & 63) == 0) { out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0; out[blockIdx.x * 16 + 8 + (threadIdx.x >> 6)] = r1 - r0; }
 }
 
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// the 16x16x32 form (4 passes = 16 cycles, 4 accumulator registers per tile) on random operands, 4 chains
+__global__ void k16(unsigned long long *out, int iters, float *sink) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    unsigned x = (threadIdx.x * 2654435761u) ^ (i * 40503u) ^ (blockIdx.x * 97u);
+    x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+    a[i] = (__bf16)(((int)(x & 0xffff) - 32768) * 3.1e-5f);
+    b[i] = (__bf16)(((int)(x >> 16) - 32768) * 3.1e-5f);
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i & 3], 0, 0, 0);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  if (s == 123.456f) sink[0] = s;
+  if ((threadIdx.x & 63) == 0) { out[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0; out[blockIdx.x * 16 + 8 + (threadIdx.x >> 6)] = r1 - r0; }
+}
+
 int main() {
   unsigned long long *d, h[16 * 128];
   float *sink;
@@ -70,5 +101,20 @@ int main() {
       printf("%-40s %d wave(s)/SIMD: %6.1f s_memtime ticks per MFMA per wave; s_memtime / s_memrealtime = %.2f (x 100 MHz = shader clock); kernel %.3f ms -> %.0f TFLOP/s\n",
              what[chains], threads / 256, per, (double)h[0] / (double)h[8], ms, tf);
     }
+  for (int threads = 256; threads <= 512; threads *= 2) {
+    float ms = 0.f;
+    const int its = iters * 100;
+    for (int rep = 0; rep < 2; ++rep) {
+      (void)hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(k16, dim3(256), dim3(threads), 0, 0, d, its, sink);
+      (void)hipEventRecord(e1, 0);
+      (void)hipDeviceSynchronize();
+      (void)hipEventElapsedTime(&ms, e0, e1);
+    }
+    (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    const double tf = 2.0 * 16 * 16 * 32 * 24.0 * its * (threads / 64) * 256 / (ms * 1e-3) / 1e12;
+    printf("%-40s %d wave(s)/SIMD: %6.1f s_memtime ticks per MFMA per wave; s_memtime / s_memrealtime = %.2f (x 100 MHz = shader clock); kernel %.3f ms -> %.0f TFLOP/s\n",
+           "16x16x32, 4 chains, random operands, 100x longer", threads / 256, (double)h[0] / its / 24.0, (double)h[0] / (double)h[8], ms, tf);
+  }
   return 0;
 }
