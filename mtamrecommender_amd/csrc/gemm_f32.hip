@@ -738,6 +738,8 @@ extern "C" int mtam_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int
                                      void *stream) {
   MTAM_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch0 > 0 && batch1 > 0, "gemm_batched: bad sizes");
   MTAM_CHECK_ARG(A && B && C, "gemm_batched: null operand");
+  const bool x3 = (epilogue & MTAM_GEMM_SPLIT_BF16) != 0 && split_enabled();
+  epilogue &= ~MTAM_GEMM_SPLIT_BF16;
   MTAM_CHECK_ARG(epilogue == MTAM_EPI_STORE || epilogue == MTAM_EPI_ACCUM, "gemm_batched: STORE or ACCUM only");
   MTAM_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "gemm_batched: bad leading dimension");
   MTAM_CHECK_ARG((long)batch0 * batch1 <= 65535, "gemm_batched: at most 65535 problems per launch");
@@ -756,7 +758,8 @@ extern "C" int mtam_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int
   a.vecC = 0;
   dim3 grid((unsigned)(gx * gy), (unsigned)(batch0 * batch1), 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  launch_trans<1, false>(trans_a, trans_b, epilogue, grid, s, a);
+  if (x3) launch_trans<1, true>(trans_a, trans_b, epilogue, grid, s, a);
+  else    launch_trans<1, false>(trans_a, trans_b, epilogue, grid, s, a);
   MTAM_CHECK_LAUNCH("gemm_batched");
   return MTAM_OK;
 }

@@ -85,10 +85,12 @@ def gemm_sq_partials(M, N):
 
 
 def gemm_batched(a, b, c, M, N, K, lda, sa, ldb, sb, ldc, sc, batch, trans_a=False, trans_b=False,
-                 epilogue=EPI_STORE):
+                 epilogue=EPI_STORE, split=True):
     """batch = (batch0, batch1); sa/sb/sc = (stride over batch0, stride over batch1) in elements.
-    a, b, c: base tensors (any shape, contiguous storage)."""
+    a, b, c: base tensors (any shape, contiguous storage).  ``split``: as in ``gemm``."""
     lib = _lib.load()
+    if split:
+        epilogue |= GEMM_SPLIT_BF16
     rc = lib.mtam_gemm_f32_batched(int(trans_a), int(trans_b), M, N, K, _p(a), lda, sa[0], sa[1], _p(b), ldb,
                                    sb[0], sb[1], _p(c), ldc, sc[0], sc[1], batch[0], batch[1], epilogue,
                                    _stream())

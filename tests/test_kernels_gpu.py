@@ -124,15 +124,18 @@ def test_gemm_submatrix_views(ops):
     assert rel_err(C.cpu().numpy(), ref) < 2e-6
 
 
-def test_gemm_batched(ops):
+@pytest.mark.parametrize("split", [False, True])
+def test_gemm_batched(ops, split):
     """(sample, head) batches over sub-matrices of packed buffers, as the self-attention encoder uses them."""
+    import functools
+    gemm_batched = functools.partial(ops.gemm_batched, split=split)
     rng = np.random.default_rng(21)
     Bn, H, L, d = 3, 4, 37, 32
     Dm = H * d
     qkv = rng.standard_normal((Bn * L, 3 * Dm)).astype(np.float32)
     out = torch.full((Bn, H, L, L), 9.0, device="cuda")
     qd = dev(qkv)
-    ops.gemm_batched(qd, qd.view(-1)[Dm:], out, L, L, d, 3 * Dm, (L * 3 * Dm, d), 3 * Dm, (L * 3 * Dm, d), L,
+    gemm_batched(qd, qd.view(-1)[Dm:], out, L, L, d, 3 * Dm, (L * 3 * Dm, d), 3 * Dm, (L * 3 * Dm, d), L,
                      (H * L * L, L * L), (Bn, H), trans_b=True)
     q3 = qkv.reshape(Bn, L, 3 * Dm).astype(np.float64)
     ref = np.einsum("bihc,bjhc->bhij", q3[:, :, :Dm].reshape(Bn, L, H, d), q3[:, :, Dm:2 * Dm].reshape(Bn, L, H, d))
@@ -141,13 +144,13 @@ def test_gemm_batched(ops):
     w = rng.standard_normal((Bn, H, L, L)).astype(np.float32)
     o0 = rng.standard_normal((Bn * L, Dm)).astype(np.float32)
     o = dev(o0).clone()
-    ops.gemm_batched(dev(w), qd.view(-1)[2 * Dm:], o, L, d, L, L, (H * L * L, L * L), 3 * Dm, (L * 3 * Dm, d), Dm,
+    gemm_batched(dev(w), qd.view(-1)[2 * Dm:], o, L, d, L, L, (H * L * L, L * L), 3 * Dm, (L * 3 * Dm, d), Dm,
                      (L * Dm, d), (Bn, H), epilogue=ops.EPI_ACCUM)
     v = q3[:, :, 2 * Dm:].reshape(Bn, L, H, d)
     ref = o0.reshape(Bn, L, H, d) + np.einsum("bhij,bjhc->bihc", w.astype(np.float64), v)
     assert rel_err(o.cpu().numpy().reshape(Bn, L, H, d), ref) < 2e-6
     o2 = torch.zeros((Bn * L, Dm), device="cuda")
-    ops.gemm_batched(dev(w), qd.view(-1)[2 * Dm:], o2, L, d, L, L, (H * L * L, L * L), 3 * Dm, (L * 3 * Dm, d), Dm,
+    gemm_batched(dev(w), qd.view(-1)[2 * Dm:], o2, L, d, L, L, (H * L * L, L * L), 3 * Dm, (L * 3 * Dm, d), Dm,
                      (L * Dm, d), (Bn, H), trans_a=True)
     ref = np.einsum("bhji,bjhc->bihc", w.astype(np.float64), v)
     assert rel_err(o2.cpu().numpy().reshape(Bn, L, H, d), ref) < 2e-6
