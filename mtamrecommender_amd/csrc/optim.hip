@@ -107,6 +107,16 @@ __global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restric
   __shared__ double dred[4];
   __shared__ int s_last;
   const size_t base = (size_t)blockIdx.x * NORM_BLOCK;
+  // The loss inputs (the lookups' L2 partials, the per-row cross entropies) were written by earlier kernels of the
+  // step: when they fit one batch of loads EVERY workgroup fetches them here, beside its gradient block, so that
+  // the last one to arrive does not pay two more round trips after the ticket (a few KB of L2 reads per workgroup)
+  const bool early_loss = loss && n_l2 <= 256 * 8 && B <= 256;
+  float pre_l2[8], pre_ce = 0.f;
+  if (early_loss) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pre_l2[q] = l2_partial[min((int)threadIdx.x + 256 * q, max(n_l2 - 1, 0))];
+    pre_ce = ce[min((int)threadIdx.x, B - 1)];
+  }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NORM_BLOCK / 1024; ++i) {
@@ -162,7 +172,11 @@ __global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restric
   // the loss inputs were written by earlier kernels of the step: issue their loads before the reduction
   // of `t` needs a barrier
   double a_l2 = 0.0, c_ce = 0.0;
-  if (loss) {
+  if (early_loss) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a_l2 += ((int)threadIdx.x + 256 * q < n_l2) ? (double)pre_l2[q] : 0.0;
+    c_ce = ((int)threadIdx.x < B) ? (double)pre_ce : 0.0;
+  } else if (loss) {
     a_l2 = sum_plain(l2_partial, n_l2);
     c_ce = sum_plain(ce, B);
   }
