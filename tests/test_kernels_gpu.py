@@ -60,14 +60,18 @@ def test_gemm_is_ordered_fma_chain(ops):
     assert np.array_equal(C.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("split", [False, True])
-def test_gemm_epilogues(ops, split):
+@pytest.mark.parametrize("split,tb", [(False, False), (True, False), (True, True)])
+def test_gemm_epilogues(ops, split, tb):
+    """tb: B stored [N, K] (C = A B^T) -- with split operands and few tiles that is the 32 x 64 tiling."""
     import functools
-    ops_gemm = functools.partial(ops.gemm, split=split)
     rng = np.random.default_rng(11)
     M, N, K = 150, 200, 96
     A = rng.standard_normal((M, K)).astype(np.float32)
     Bm = rng.standard_normal((K, N)).astype(np.float32)
+    Bdev = dev(np.ascontiguousarray(Bm.T)) if tb else dev(Bm)
+
+    def ops_gemm(a, b_unused, c, **kw):
+        return ops.gemm(a, Bdev, c, trans_b=tb, split=split, **kw)
     bias = rng.standard_normal(N).astype(np.float32)
     aux = rng.standard_normal((M, N)).astype(np.float32)
     c0 = rng.standard_normal((M, N)).astype(np.float32)
