@@ -887,7 +887,7 @@ def test_gather_reads_item_rows_from_the_bf16_copy(ops):
 
 
 @pytest.mark.parametrize("B,V", [(128, 3709), (100, 1000), (37, 63), (256, 7001), (130, 70007), (128, 200003),
-                                 (61, 65536)])
+                                 (61, 65536), (1, 17), (3, 32), (129, 33)])
 @pytest.mark.parametrize("form", ["split", "native"])
 def test_score32_lse_and_backward(ops, B, V, form):
     """csrc/score32.hip (fp32 logits-free scoring) against float64 products of the same fp32 operands:
