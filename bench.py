@@ -9,9 +9,24 @@ Adam on every variable) on a batch of 128 synthetic ml-1m-shaped sequences per
 GPU (seq_len 50, emb 128, fp32).  Inputs are resident in HBM before the timed
 region; the region is bracketed by barrier + synchronize, the slowest rank's
 time counts, and rank 0 prints one JSON line.  value = sequences/s over all
-ranks.  Extra objects on the same line:
-  roofline      embedding gather kernel: algorithmic bytes / HIP-event time vs HBM peak
-  cpu_baseline  the CPU restatement of the TF1.14 graph (oracle) timed on the host cores
+ranks.
+
+Launching.  With --gpus N > 1 and no WORLD_SIZE in the environment this file is
+its own launcher: the parent starts N children of itself (one process per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set) BEFORE
+anything touches a GPU -- it imports neither torch nor the package -- relays
+rank 0's JSON line to stdout and exits with the worst child's return code.
+Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(WORLD_SIZE set) it is one rank.  The reference's only launcher starts one
+process per GPU the same way (run_server.py:46-99).
+`--launch-selftest` exercises launcher + rendezvous + line relay with gloo ranks
+on a stub step (no GPU): tests/test_bench_launcher.py.
+
+Extra objects on the result line:
+  roofline            embedding gather kernel at the step's batch: algorithmic bytes / HIP-event time vs HBM peak
+  roofline_at_scale   the same gather and scatter-add kernels at 512 and 2,048 sequences per launch
+  gru_serial_model    the serial GRU pair against a dependent-chain model (not a roofline)
+  cpu_baseline        the CPU restatement of the TF1.14 graph (oracle) timed on the host cores
 """
 import argparse
 import json
@@ -87,6 +102,108 @@ def pmc_traffic(kernel):
     except (KeyError, ValueError, OSError):
         pass
     return None
+
+
+SCALE_LEGS = [(512, "run", "zipf"), (2048, "run", "zipf"), (512, "1m", "zipf"), (2048, "1m", "zipf"),
+              (512, "1m", "uniform"), (2048, "1m", "uniform")]
+ROT_BYTES = 768 << 20          # distinct streamed bytes in rotation per leg: 3 x the 256 MiB Infinity Cache
+
+
+def pmc_scale_traffic(key, kernel):
+    """Per-launch HBM bytes of one roofline_at_scale leg from the committed PMC passes
+    (profiles/r*_pmc_emb_scale*.json: {"B512_V3709_zipf": {"gather": {..."traffic_bytes"}, "scatter": ...}})."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_emb_scale*.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))[key][kernel]["traffic_bytes"])
+    except (KeyError, ValueError, OSError, TypeError):
+        return None
+
+
+def emb_scale_legs(ops, torch, device, run_tables, reg):
+    """`roofline_at_scale`: the stand-alone gather and scatter-add kernels (through their C entry points) at 512 and
+    2,048 sequences per launch, L = 50, D = 128 -- the sizes at which the launch is bandwidth-bound rather than a
+    latency chain -- over the run's own tables (ml-1m sized: table reads are L2 hits, as in the real step) and
+    over a 1,000,003-row item table (512 MB; with uniform ids the row reads are HBM reads too).  Every launch of
+    the timed graph works on its own id set and its own streamed buffers, ROT_BYTES of them in rotation.
+    Algorithmic bytes per SURVEY.md 8(d); `traffic` from the committed --pmc passes of the same cases
+    (tools/emb_roofline.py pmc)."""
+    from mtamrecommender_amd.data.synthetic import make_id_batch
+    Ls = 50
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
+    big = None
+    out = []
+    for B, which, dist in SCALE_LEGS:
+        if which == "run":
+            T = run_tables
+        else:
+            if big is None:
+                big = dict(run_tables, item=f32(1000003, D).uniform_(-0.2, 0.2))
+            T = big
+        V = T["item"].shape[0]
+        G = {k: torch.zeros_like(v) for k, v in T.items()} if which == "run" else \
+            dict({k: torch.zeros_like(v) for k, v in run_tables.items() if k != "item"}, item=torch.zeros_like(T["item"]))
+        R = B * Ls
+        n_g = max(2, ROT_BYTES // (R * 3 * D * 4) + 1)           # gather streams its outputs
+        n_s = max(2, ROT_BYTES // (R * 3 * D * 4 * 2) + 1)       # scatter-add its gradient rows AND the looked-up rows
+        nset = max(n_g, n_s)
+        ids = []
+        for i in range(nset):
+            c = make_id_batch(B, Ls, V, T["category"].shape[0], T["user"].shape[0], dist, seed=1234 + i)
+            ids.append({k: torch.from_numpy(v).to(device) for k, v in c.items() if k != "live_rows"})
+        outs = [(f32(R, 2 * D), f32(R, D), f32(B, D)) for _ in range(nset)]
+        l2p = torch.zeros(ops.emb_gather_partials(B, Ls), device=device)
+
+        def gather_fn(i):
+            f, (ic, pos, user) = ids[i], outs[i]
+            return lambda: ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], f["item_list"],
+                                              f["category_list"], f["position_list"], f["user_id"], B, Ls, 1,
+                                              ic, pos, user, l2p)
+        reps = 40 if B <= 512 else 12
+        t_g = time_kernel([gather_fn(i) for i in range(n_g)], torch, reps=reps, replays=10)
+        grads_in = [(f32(R, 2 * D).normal_(0, 1e-3), f32(R, D).normal_(0, 1e-3)) for _ in range(n_s)]
+        part = torch.zeros(ops.emb_scatter_partials(B, Ls), device=device)
+
+        def scatter_fn(i):
+            f, (ic, pos, user), (d_ic, d_x) = ids[i], outs[i], grads_in[i]
+            return lambda: ops.emb_scatter_add_bwd(d_ic, d_x, ic, pos, user, f["item_list"], f["category_list"],
+                                                   f["position_list"], f["user_id"], f["seq_length"], B, Ls, reg, 1,
+                                                   G["item"], G["category"], G["position"], G["user"], part)
+        t_s = time_kernel([scatter_fn(i) for i in range(n_s)], torch, reps=reps, replays=10)
+        gb, sb = gather_bytes_per_seq(Ls, D) * B, scatter_bytes_per_seq(Ls, D) * B
+        key = "B%d_V%d_%s" % (B, V, dist)
+        for kernel, t, nb, n in (("emb_gather_kernel", t_g, gb, n_g), ("emb_scatter_kernel", t_s, sb, n_s)):
+            out.append({"kernel": kernel, "sequences_per_launch": B, "seq_len": Ls, "item_rows": V, "id_dist": dist,
+                        "bound": "hbm", "achieved": nb / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": nb / t / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": nb, "us_per_launch": t * 1e6,
+                        "buffer_sets": n, "traffic": pmc_scale_traffic(key, kernel.split("_")[1])})
+        log("at scale %s: gather %.1f us (%.2f of peak), scatter-add %.1f us (%.2f)"
+            % (key, t_g * 1e6, gb / t_g / 8e12, t_s * 1e6, sb / t_s / 8e12))
+        del ids, outs, grads_in, G
+        torch.cuda.empty_cache()
+    return out
+
+
+def gru_serial_model(L_, ms_fwd, ms_bwd, clock_ghz=2.3):
+    """The time-aware GRU against a dependent-chain model (latency-bound, not a roofline).
+    One workgroup per sample walks L-1 steps; a step is one wave's chain of DEPENDENT instructions:
+      gate contraction   32 v_pk_fma_f32 per wave at 8.5 cycles issue, two waves sharing a SIMD   (~770 cycles measured)
+      octet reduction    3 DPP adds + sigmoid (exp, rcp) at 15-17 cycles per dependent VALU op     (~300)
+      candidate          r.h through LDS, 16 v_pk_fma_f32, reduction, tanh                          (~410)
+      update + barriers  u h + (1-u) c T, two s_barrier                                             (~490)
+    Model cycles per step = the sum of the per-phase FLOORS (issue intervals from profiles/r02_valu_issue_lab.txt):
+    32 x 8.5 x 2 + 7 x 16 + (16 x 8.5 x 2 + 7 x 16) + 2 x 64 + 10 x 16 = 1,328; achieved = kernel time / (L-1)
+    at the clock the stamps were taken at."""
+    steps = L_ - 1
+    model = 32 * 8.5 * 2 + 7 * 16 + (16 * 8.5 * 2 + 7 * 16) + 2 * 64 + 10 * 16
+    to_cycles = lambda ms: ms * 1e-3 * clock_ghz * 1e9 / steps
+    return {"kernel": "tagru_fwd_kernel + tagru_bwd_kernel", "bound": "serial dependent chain (not a roofline)",
+            "steps_per_launch": steps, "clock_ghz_assumed": clock_ghz, "model_cycles_per_step": model,
+            "achieved_cycles_per_step_fwd": to_cycles(ms_fwd), "achieved_cycles_per_step_bwd": to_cycles(ms_bwd),
+            "frac_fwd": model / to_cycles(ms_fwd), "us_fwd": ms_fwd * 1e3, "us_bwd": ms_bwd * 1e3,
+            "stamps": "profiles/r02_gru_lab_stamps_v4_final.txt"}
 
 
 def host_cores():
@@ -165,6 +282,100 @@ def cpu_baseline(records_batches, FLAGS, arrays, budget_s=15.0, model_name="MTAM
                       % (len(timed), B_PER_GPU, med * 1e3)}
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(n, argv):
+    """Parent of an N-rank run: start N children of this file, one per GPU, and relay rank 0's result line.
+    Nothing here may touch a GPU (no torch import, no package import): a process that has initialised HIP must
+    not fork/exec workers on this pool.  Children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    (what torch.distributed.run would set; the reference's launcher is likewise one process per GPU,
+    run_server.py:46-99).  Rank 0's stdout is piped and its last JSON line re-printed; every other stream goes to
+    this process's stderr.  If a child fails, the others are terminated by PID (they would otherwise wait in a
+    collective until the RCCL timeout) and the worst return code is this process's."""
+    import signal
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
+    children = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   MTAM_BENCH_CHILD="1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                         stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    log("launcher: %d ranks started (pids %s), rendezvous 127.0.0.1:%d" % (n, [c.pid for c in children], port))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(children[0].stdout.read().decode().splitlines()))
+    reader.start()
+    rcs, failed, first_rc = [None] * n, False, 0
+    while any(rc is None for rc in rcs):
+        for i, c in enumerate(children):
+            if rcs[i] is None:
+                rcs[i] = c.poll()
+                if rcs[i] not in (None, 0) and not failed:
+                    failed, first_rc = True, abs(rcs[i])
+                    log("launcher: rank %d exited with %d: stopping the other ranks" % (i, rcs[i]))
+                    for j, o in enumerate(children):
+                        if rcs[j] is None and o.poll() is None:
+                            o.send_signal(signal.SIGTERM)
+        time.sleep(0.05)
+    reader.join()
+    result = [ln for ln in lines if ln.startswith("{")]
+    for ln in lines:
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    worst = first_rc if failed else 0             # (the ranks stopped by SIGTERM report -15: not the cause)
+    if worst == 0 and len(result) != 1:
+        log("launcher: expected one result line from rank 0, got %d" % len(result))
+        worst = 1
+    if worst == 0:
+        sys.stdout.write(result[-1] + "\n")
+        sys.stdout.flush()
+    return worst
+
+
+def selftest_rank(args):
+    """--launch-selftest: one rank of a stub run -- gloo on the CPU, a sleep for a step -- through the same
+    barrier / max-over-ranks / one-line protocol as the real thing (the launcher's CPU test)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if os.environ.get("MTAM_SELFTEST_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                      # a rank that dies before the rendezvous: the launcher must not hang
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    print("rank %d chatter on stdout (must not reach the result line)" % rank)
+    for _ in range(args.warmup):
+        time.sleep(1e-3)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3 * (1 + rank))            # the slowest rank's time counts
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(per_rank, torch.tensor([elapsed], dtype=torch.float64))
+    seen = torch.ones(1)
+    dist.all_reduce(seen)
+    worst = max(float(t) for t in per_rank)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest (stub step)", "value": B_PER_GPU * world * args.steps / worst,
+                          "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": worst / args.steps * 1e3, "ranks_seen": int(seen.item()),
+                          "ms_per_step_by_rank": [float(t) / args.steps * 1e3 for t in per_rank]}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,9 +392,18 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--score-dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: logits-free bf16-MFMA catalog scoring (BASELINE.json configs[4]); default fp32")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="stub ranks over gloo, no GPU: checks launcher, rendezvous and the one-line protocol")
+    ap.add_argument("--no-scale-legs", action="store_true", help="skip roofline_at_scale (B = 512 / 2,048 legs)")
     args = ap.parse_args()
     global L, NB, H, B_PER_GPU
     L, NB, H, B_PER_GPU = args.seq_len, args.blocks, args.heads, args.batch
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(args.gpus, sys.argv[1:]))          # parent: no GPU call before or after this line
+    if args.launch_selftest:
+        return selftest_rank(args)
 
     # Only the result line may reach stdout: RCCL prints a version banner to stdout when it creates its
     # first communicator, and torch / ROCm libraries may print too.  Everything else goes to stderr.
@@ -197,8 +417,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (see the module docstring)")
+        raise SystemExit("WORLD_SIZE=%d in the environment but --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     # MTAM_BENCH_FORCE_DP=1: run the multi-GPU code path (RCCL group, gradient exchange, barriers, max over
@@ -279,7 +498,15 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ranks_seen, per_rank_ms = 1, [elapsed / args.steps * 1e3]
     if use_dist:
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        every = torch.zeros(max(world, 1), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(every, mine)
+        per_rank_ms = [float(t) / args.steps * 1e3 for t in every.cpu()]
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
         elapsed = data_parallel.max_over_ranks(elapsed, device)
 
     log("rank %d: timed region %.3f s for %d steps" % (rank, elapsed, args.steps))
@@ -354,12 +581,30 @@ def main():
         log("gather %.2f us (one buffer set re-used: %.2f), scatter-add %.2f us (%.2f) per launch"
             % (t_gather * 1e6, t_gather_hot * 1e6, t_scatter * 1e6, t_scatter_hot * 1e6))
         recall = model.recall_at(model.sess, batches[0], 20)
+        gru_model = None
+        if args.model == "MTAM" and p.cfg["gru"] == "time":
+            tvec = p.seg("gru/tvec")
+            t_gf = time_kernel(lambda: ops.tagru_fwd(bt.xproj, bt.x, fd["timelast_list"], fd["seq_length"],
+                                                     p.seg("gru/wh_g"), p.seg("gru/wh_c"), tvec, B_PER_GPU, L, bt.hs,
+                                                     bt.short, bt.gru_save), torch, reps=20, replays=10)
+            t_gb = time_kernel(lambda: ops.tagru_bwd(bt.d_dec[0], bt.x, fd["timelast_list"], fd["seq_length"],
+                                                     p.seg("gru/wh_g"), p.seg("gru/wh_c"), tvec, bt.gru_save,
+                                                     B_PER_GPU, L, bt.d_xproj, bt.rh, bt.d_xt, bt.d_tvec_partial),
+                               torch, reps=20, replays=10)
+            gru_model = gru_serial_model(L, t_gf * 1e3, t_gb * 1e3)
+            log("GRU forward %.1f us, backward %.1f us per launch" % (t_gf * 1e6, t_gb * 1e6))
         result = {
             "metric": "training sequences/sec", "value": B_PER_GPU * world * args.steps / elapsed,
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.score_dtype == "f32" else "bf16 scoring operands, f32 accumulate and elsewhere",
-            "data": "synthetic",
+            "arith": ("training GEMMs and catalog scoring: fp32 via 3 x bf16 split operands (6 bf16-MFMA terms per "
+                      "product, each exact), fp32 accumulate -- fp32-equivalent (tested to fp64 within 2x a native "
+                      "fp32 matmul's error); fused forward projections: native fp32 MFMA; GRU / attention / "
+                      "optimizer / lookups: fp32 VALU; evaluation scores: k-ordered fp32 fmaf chain"),
+            "data": "synthetic", "ranks_seen": ranks_seen, "ms_per_step_by_rank": per_rank_ms,
+            "exchange": (None if not use_dist else "row-sharded item exchange (reduce-scatter + owned Adam + "
+                         "all-gather)" if p.sharded is not None else "flat all-reduce of every gradient"),
             "config": {"workload": "%s training step, %s synthetic (%d items, %d categories, %d users), seq_len=%d "
                                    "emb=128 num_blocks=%d num_heads=%d, batch=%d per GPU"
                                    % ("MTAMRec" if args.model == "MTAM" else "PISTRec (Time_Aware_self_Attention_model)",
@@ -368,14 +613,17 @@ def main():
                        "global_batch": B_PER_GPU * world, "seq_len": L, "parallelism": "dp%d" % world,
                        "id_dist": args.id_dist, "optimizer": "adam", "hipgraph": bool(model.use_graph),
                        "dp_graph": getattr(model, "_dp_mode", None) if use_dist else None},
-            "recall_at_20": recall, "loss_first": loss_first, "loss_last": loss_last,
+            "recall_at_20_train_batch_smoke": recall,
+            "recall_note": "Recall@20 of TRAINING batch 0 after the timed steps on synthetic records: a smoke value "
+                           "(the model fits its 32 batches), not BASELINE's ml-1m Recall@20 -- the dataset is not here",
+            "loss_first": loss_first, "loss_last": loss_last,
             "roofline": {"kernel": "emb_gather_kernel", "bound": "hbm", "achieved": gb / t_gather / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / t_gather / 1e9 / HBM_PEAK_GBS,
                          "traffic": pmc_traffic("emb_gather_kernel") if (L, B_PER_GPU) == (50, 128) else None,
                          "bytes_per_launch": gb, "us_per_launch": t_gather * 1e6,
                          "buffer_sets": n_rot, "us_per_launch_cache_hot": t_gather_hot * 1e6,
                          "note": "latency-bound at 128 sequences per launch (a 1.7 us empty kernel in the same "
-                                 "harness); HBM-bound sizes: profiles/r02_emb_sweep_*.jsonl"},
+                                 "harness); the bandwidth-bound sizes are in roofline_at_scale"},
             "roofline_scatter_add": {"kernel": "emb_scatter_kernel", "bound": "hbm", "achieved": sb / t_scatter / 1e9,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": sb / t_scatter / 1e9 / HBM_PEAK_GBS,
@@ -384,6 +632,10 @@ def main():
                                      "bytes_per_launch": sb, "us_per_launch": t_scatter * 1e6,
                                      "buffer_sets": n_rot_s, "us_per_launch_cache_hot": t_scatter_hot * 1e6},
         }
+        if gru_model is not None:
+            result["gru_serial_model"] = gru_model
+        if not args.no_scale_legs and args.score_dtype == "f32":
+            result["roofline_at_scale"] = emb_scale_legs(ops, torch, device, T, p.reg)
         if fused is not None:
             result["roofline_fused_forward"] = fused
             log("fused lookups + projections: %.2f us per launch (%.1f TFLOP/s)" % (t_fused * 1e6, fused["achieved"]))

@@ -426,14 +426,17 @@ int mtam_score16_logits(const uint16_t *E16, const uint16_t *P16, int B, int V, 
  * at load, the setter at run time).  The buffer sizes below depend on the form: set it before sizing.
  * Evaluation keeps the stored-logits GEMM (its k-ordered fmaf chain is the ranking contract of mtam_topk).
  *   partial: mtam_score32_partials(B, V) floats; sq_partial: mtam_score32_sq_partials(V) floats or NULL;
+ *   n_partial / n_sq_partial: how many floats the caller's buffers hold -- checked against the CURRENT form's
+ *   counts (n_partial >=, n_sq_partial ==: its consumer sums exactly that many), so a buffer sized before
+ *   mtam_score32_set_split_min_rows() changed the form is rejected instead of overrun;
  *   d_pred is accumulated (the caller zeroes it), dE [V, 128] is stored. */
 void mtam_score32_set_split_min_rows(long min_rows);
 int mtam_score32_partials(int B, int V);
 int mtam_score32_sq_partials(int V);
 int mtam_score32_lse(const float *E, const float *pred, const int32_t *target, int B, int V, float *partial,
-                     float *lse, float *ce, void *stream);
+                     int n_partial, float *lse, float *ce, void *stream);
 int mtam_score32_bwd(const float *E, const float *pred, const float *lse, const int32_t *target, int B, int V,
-                     float scale, float *d_pred, float *dE, float *sq_partial, void *stream);
+                     float scale, float *d_pred, float *dE, float *sq_partial, int n_sq_partial, void *stream);
 
 /* ------------------------------------------- the forward's three sequence-side projections in one launch
  *   zr = relu(ic W4) ; x = zr + pos                       (Embedding/...attention.py:95-103; = mtam_gemm_f32 RELU_ADD)

@@ -224,6 +224,14 @@ class NativeDataInput(object):
         sizes = {min(self.batch_size, n), n % self.batch_size}
         if shard is not None:
             rank, world = shard
+            # A last global batch smaller than the world size would leave some ranks with NO samples: they would
+            # skip (or fail) the step while the others wait inside the gradient exchange.  The decision is taken
+            # on the GLOBAL batch, so every rank takes the same branch: such a batch is dropped everywhere
+            # (data_parallel.keep_global_batch; at most world - 1 records per epoch).
+            tail = n % self.batch_size
+            if 0 < tail < world:
+                self.epoch_size -= 1
+                sizes.discard(tail)
             sizes = {(g * (rank + 1)) // world - (g * rank) // world for g in sizes}
         for size in sizes:
             if size > 0:

@@ -45,6 +45,8 @@ class SummaryWriter(object):
         if not summary:
             return
         for tag, value in summary.items():
+            if tag == "loss_step":           # which step the values belong to (async_loss): the row key, not a value
+                continue
             self.rows.append((global_step, tag, float(value)))
         if self.path is not None and len(self.rows) >= 256:
             self.flush()
@@ -79,12 +81,13 @@ class base_model(object):
         self.use_graph = os.environ.get("MTAM_HIP_GRAPH", "1") != "0"
         self._dp_mode = os.environ.get("MTAM_DP_GRAPH")       # None: decided at the first data-parallel step
         self._graphs = {}
-        # async_loss: train() hands back the loss of the PREVIOUS step (its own on the first call) instead of
-        # blocking on this step's -- the reference's sess.run blocks (:159-164), and with a blocking read-back the
-        # host cannot prepare batch t + 1 while the device runs step t.  Off by default (drop-in semantics);
-        # Train_main_process, which only averages and logs the losses, turns it on.  last_loss() drains.
+        # async_loss: train() hands back the loss of the PREVIOUS step (with the global_step it belongs to; nothing
+        # on the first call) instead of blocking on this step's -- the reference's sess.run blocks (:159-164), and
+        # with a blocking read-back the host cannot prepare batch t + 1 while the device runs step t.  Off by
+        # default (drop-in semantics); Train_main_process, which only averages and logs the losses, turns it on
+        # and calls drain_loss() wherever it needs the most recent step's.
         self.async_loss = False
-        self._loss_ring, self._loss_slot, self._steps_issued = None, 0, 0
+        self._loss_ring, self._loss_slot, self._loss_unread, self.loss_step = None, 0, False, None
 
     # ------------------------------------------------------------ life cycle
     def init_variables(self, sess, path, var_list=None):
@@ -311,38 +314,67 @@ class base_model(object):
         return p.load_feed(input_dic, learning_rate), input_dic[self.embedding.target_item_id]
 
     def train(self, sess, batch_data, learning_rate, add_summary=False, global_step=0, epoch=0):
-        """One optimizer step on one batch -> (loss, summary) (reference :150-167)."""
+        """One optimizer step on one batch -> (loss, summary) (reference :150-167).
+
+        With ``async_loss`` the pair belongs to the PREVIOUS step (``summary["loss_step"]`` / ``self.loss_step`` say
+        which ``global_step``); the first call returns ``(nan, {"loss_step": None})`` -- nothing has finished yet --
+        and ``drain_loss()`` hands over the most recent step's once the loop ends (or before a checkpoint)."""
         bt, _ = self._load(batch_data, learning_rate)
         self.step_train(bt)
         if self.async_loss:
-            loss = self._loss_one_step_late(bt)
+            loss, step, lr = self._loss_one_step_late(bt, global_step, learning_rate)
+            if loss is None:
+                self.loss_step = None
+                return float("nan"), {"loss_step": None}
         else:
-            loss = bt.loss.cpu().numpy()
-        summary = {"normalized Training Loss": float(loss[0]), "l2_norm": float(loss[1]),
-                   "Training Loss": float(loss[2]), "Learning_rate": float(learning_rate)}
-        return float(loss[0]), summary
+            loss, step, lr = bt.loss.cpu().numpy(), global_step, learning_rate
+        self.loss_step = step
+        return float(loss[0]), self._summary(loss, lr, step)
 
-    def _loss_one_step_late(self, bt):
+    @staticmethod
+    def _summary(loss, learning_rate, step):
+        return {"normalized Training Loss": float(loss[0]), "l2_norm": float(loss[1]),
+                "Training Loss": float(loss[2]), "Learning_rate": float(learning_rate), "loss_step": step}
+
+    def _loss_one_step_late(self, bt, global_step, learning_rate):
         """Queue a device -> pinned-host copy of this step's loss behind the step and return the previous step's
-        (two pinned slots, one event each): the host never waits for the step it has just launched."""
+        (two pinned slots, one event each): the host never waits for the step it has just launched.
+        -> (loss[3], the global_step it belongs to, that step's learning rate), or (None, None, None) on the
+        first call."""
         if self._loss_ring is None:
-            self._loss_ring = [(torch.zeros(3).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+            self._loss_ring = [[torch.zeros(3).pin_memory(), torch.cuda.Event(), None, None] for _ in range(2)]
         cur = self._loss_slot
-        host, ev = self._loss_ring[cur]
-        host.copy_(bt.loss, non_blocking=True)
-        ev.record()
-        first = self._steps_issued == 0
-        self._steps_issued += 1
+        slot = self._loss_ring[cur]
+        slot[0].copy_(bt.loss, non_blocking=True)
+        slot[1].record()
+        slot[2], slot[3] = global_step, learning_rate
         self._loss_slot = 1 - cur
-        host, ev = self._loss_ring[cur if first else 1 - cur]
+        self._loss_unread = True
+        prev = self._loss_ring[1 - cur]
+        if prev[2] is None:
+            return None, None, None
+        prev[1].synchronize()
+        return prev[0].numpy().copy(), prev[2], prev[3]
+
+    def drain_loss(self):
+        """(loss, summary) of the most recent step when train() has not handed it over yet (``async_loss``), else
+        None; waits for that step.  The trainer calls it before it averages, evaluates, saves or ends an epoch."""
+        if self._loss_ring is None or not self._loss_unread:
+            return None
+        host, ev, step, lr = self._loss_ring[1 - self._loss_slot]
         ev.synchronize()
-        return host.numpy().copy()
+        self._loss_unread = False
+        # the next train() call must not hand this one over again
+        self._loss_ring[1 - self._loss_slot][2] = None
+        self.loss_step = step
+        loss = host.numpy().copy()
+        return float(loss[0]), self._summary(loss, lr, step)
 
     def last_loss(self):
         """The loss of the most recent step (waits for it)."""
-        if self._loss_ring is None or self._steps_issued == 0:
+        if self._loss_ring is None:
             return None
-        host, ev = self._loss_ring[1 - self._loss_slot]
+        host, ev = self._loss_ring[1 - self._loss_slot][:2]
         ev.synchronize()
         return float(host[0])
 

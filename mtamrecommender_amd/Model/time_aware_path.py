@@ -351,7 +351,7 @@ class TimeAwarePath(object):
         sq = part[self.nb_dense:] if self.tf_compat else None
         if self.logits_free32:
             ops.score32_bwd(self.tables["item"], bt.pred, bt.lse, bt.feed["target_item_id"], bt.B, V,
-                            1.0 / self.gb(bt), bt.d_pred, self.g_tab["item"], sq)
+                            1.0 / self.gb(bt), bt.d_pred, self.g_tab["item"], sq, n_sq=self.nb_item)
             return
         if self.score_dtype == "bf16":
             gb = self.gb(bt)
@@ -684,9 +684,20 @@ class TimeAwarePath(object):
         return {k: v.detach().cpu().numpy() for k, v in self.tables.items()}
 
     def optimizer_state(self):
-        return {"flat_m": self.flat_m.cpu(), "flat_v": self.flat_v.cpu(), "adam_state": self.adam_state.cpu()}
+        """Both optimizer slots over the TRUE parameter space ``[:n_total]`` (the item pad rows and the
+        data-parallel loss tail behind it are allocation details, not state) + the device-side Adam scalars."""
+        n = self.n_total
+        return {"flat_m": self.flat_m[:n].cpu(), "flat_v": self.flat_v[:n].cpu(), "adam_state": self.adam_state.cpu(),
+                "n_total": n}
 
     def load_optimizer_state(self, st):
-        self.flat_m.copy_(st["flat_m"])
-        self.flat_v.copy_(st["flat_v"])
+        """Accepts a state of length n_total (this build) or longer (a checkpoint written when the whole
+        allocation was saved: its first n_total entries are the state)."""
+        n = self.n_total
+        for name, flat in (("flat_m", self.flat_m), ("flat_v", self.flat_v)):
+            src = st[name]
+            if src.numel() < n:
+                raise ValueError("optimizer state %s has %d entries, this model needs %d" % (name, src.numel(), n))
+            flat[:n].copy_(src.reshape(-1)[:n])
+            flat[n:].zero_()
         self.adam_state.copy_(st["adam_state"])

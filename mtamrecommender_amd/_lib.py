@@ -87,8 +87,8 @@ SIGNATURES = {
     "mtam_score32_set_split_min_rows": (None, [ctypes.c_long]),
     "mtam_score32_partials": (c_int, [c_int, c_int]),
     "mtam_score32_sq_partials": (c_int, [c_int]),
-    "mtam_score32_lse": (c_int, [P, P, P, c_int, c_int, P, P, P, P]),
-    "mtam_score32_bwd": (c_int, [P, P, P, P, c_int, c_int, c_float, P, P, P, P]),
+    "mtam_score32_lse": (c_int, [P, P, P, c_int, c_int, P, c_int, P, P, P]),
+    "mtam_score32_bwd": (c_int, [P, P, P, P, c_int, c_int, c_float, P, P, P, c_int, P]),
     "mtam_score16_logits": (c_int, [P, P, c_int, c_int, P, ctypes.c_long, P]),
     "mtam_sqnorm_blocks": (c_int, [c_size_t]),
     "mtam_sqnorm_partial": (c_int, [P, c_size_t, P, P]),

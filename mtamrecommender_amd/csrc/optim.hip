@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restric
       const double ces = (dred[0] + dred[1]) + (dred[2] + dred[3]);
       loss[0] = (float)((double)reg * l2 + (double)ce_scale * ces);
       loss[1] = (float)l2;
-      loss[2] = (float)(ces / (double)B);
+      loss[2] = (float)((double)ce_scale * ces);
     }
   }
 }

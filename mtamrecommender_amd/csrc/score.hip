@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float *__restric
   if (threadIdx.x == 0) {
     loss[0] = reg * l2 + ce_scale * ces;
     loss[1] = l2;
-    loss[2] = ces / (float)B;
+    loss[2] = ce_scale * ces;          // mean over the GLOBAL batch (ce_scale = 1 / global batch; = ces / B on one GPU)
   }
 }
 
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void ce_row_loss_kernel(const float *__restric
     if (tid == 0) {
       loss[0] = reg * l2 + ce_scale * ces;
       loss[1] = l2;
-      loss[2] = ces / (float)B;
+      loss[2] = ce_scale * ces;          // mean over the GLOBAL batch (ce_scale = 1 / global batch; = ces / B on one GPU)
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

@@ -767,8 +767,11 @@ extern "C" int mtam_score32_partials(int B, int V) { return B * lse_grid_of(V) *
 extern "C" int mtam_score32_sq_partials(int V) { return grid_of(V) * 4; }
 
 extern "C" int mtam_score32_lse(const float *E, const float *pred, const int32_t *target, int B, int V,
-                                float *partial, float *lse, float *ce, void *stream) {
+                                float *partial, int n_partial, float *lse, float *ce, void *stream) {
   MTAM_CHECK_ARG(E && pred && target && partial && lse && ce, "score32_lse: null argument");
+  MTAM_CHECK_ARG(B > 0 && V > 0 && n_partial >= mtam_score32_partials(B, V),
+                 "score32_lse: partial buffer holds %d floats, this form of the pass writes %d (sized before "
+                 "mtam_score32_set_split_min_rows changed the form?)", n_partial, mtam_score32_partials(B, V));
   MTAM_CHECK_ARG(B > 0 && V > 0 && V < 0x7fffff00 && (B + BT - 1) / BT <= 65535, "score32_lse: bad shape B=%d V=%d", B, V);
   MTAM_CHECK_ARG(mtam_aligned16(E) && mtam_aligned16(pred), "score32_lse: operands must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -785,8 +788,12 @@ extern "C" int mtam_score32_lse(const float *E, const float *pred, const int32_t
 }
 
 extern "C" int mtam_score32_bwd(const float *E, const float *pred, const float *lse, const int32_t *target, int B,
-                                int V, float scale, float *d_pred, float *dE, float *sq_partial, void *stream) {
+                                int V, float scale, float *d_pred, float *dE, float *sq_partial, int n_sq_partial,
+                                void *stream) {
   MTAM_CHECK_ARG(E && pred && lse && target && d_pred && dE, "score32_bwd: null argument");
+  MTAM_CHECK_ARG(!sq_partial || (V > 0 && n_sq_partial == mtam_score32_sq_partials(V)),
+                 "score32_bwd: sq_partial holds %d floats, this form of the pass writes %d (sized before "
+                 "mtam_score32_set_split_min_rows changed the form?)", n_sq_partial, V > 0 ? mtam_score32_sq_partials(V) : 0);
   MTAM_CHECK_ARG(B > 0 && V > 0 && V < 0x7fffff00 && scale > 0.f, "score32_bwd: bad shape B=%d V=%d", B, V);
   MTAM_CHECK_ARG(mtam_aligned16(E) && mtam_aligned16(pred), "score32_bwd: operands must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -73,3 +73,24 @@ def make_records(catalog, num, max_len, seed=1234, id_dist="zipf"):
             [target_id, target_cat, target_time],
             length))
     return records
+
+
+def make_id_batch(B, L, item_rows, category_rows, user_rows, id_dist="zipf", seed=1234):
+    """Padded id arrays of one batch, drawn directly (no record tuples): what the embedding kernels' roofline
+    legs at 512 / 2,048 / 8,192 sequences per launch are fed (bench.py ``roofline_at_scale``,
+    tools/emb_roofline.py).  Same shape rules as ``make_records``: length ~ U{2..L}, Zipf(1.1) items folded by
+    modulo (or uniform), a fixed item -> category map, positions 0..len-1, zeros past the length."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sl = rng.integers(2, L + 1, size=B)
+    live = np.arange(L)[None, :] < sl[:, None]
+    if id_dist == "zipf":
+        items = np.mod(rng.zipf(1.1, size=(B, L)).astype(np.int64) - 1, item_rows - 3)
+    else:
+        items = rng.integers(0, item_rows - 3, size=(B, L))
+    cmap = np.random.Generator(np.random.PCG64(4321)).integers(0, category_rows - 3, size=item_rows)
+    cats = cmap[items]
+    pos = np.tile(np.arange(L), (B, 1))
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    return dict(item_list=i32(items * live), category_list=i32(cats * live), position_list=i32(pos * live),
+                user_id=i32(rng.integers(0, user_rows, size=B)), seq_length=i32(sl),
+                live_rows=int(live.sum()) * 3 + B)

@@ -34,6 +34,14 @@ def shard(records, rank, world):
     return records[lo:hi]
 
 
+def keep_global_batch(global_size, world):
+    """Whether a global batch is trained on.  One smaller than the world size would give some ranks an empty
+    slice -- they could not run the step while the others wait inside the collective -- so it is dropped on EVERY
+    rank (the test looks at the global size only, hence every rank agrees).  The reference keeps its last partial
+    batch (DataHandle/get_input_data.py); with one rank so does this build."""
+    return global_size >= max(1, world)
+
+
 def allreduce_gradients(buffers, group=None):
     """Sum the given gradient buffers across ranks, in place."""
     for b in buffers:

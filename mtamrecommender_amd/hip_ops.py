@@ -412,14 +412,15 @@ def score32_sq_partials(V):
 
 def score32_lse(E, pred, target, B, V, partial, lse, ce):
     lib = _lib.load()
-    _lib.check(lib.mtam_score32_lse(_p(E), _p(pred), _pi(target), B, V, _p(partial), _p(lse), _p(ce), _stream()),
-               "mtam_score32_lse")
+    _lib.check(lib.mtam_score32_lse(_p(E), _p(pred), _pi(target), B, V, _p(partial), partial.numel(), _p(lse), _p(ce),
+                                    _stream()), "mtam_score32_lse")
 
 
-def score32_bwd(E, pred, lse, target, B, V, scale, d_pred, dE, sq_partial=None):
+def score32_bwd(E, pred, lse, target, B, V, scale, d_pred, dE, sq_partial=None, n_sq=None):
     lib = _lib.load()
     _lib.check(lib.mtam_score32_bwd(_p(E), _p(pred), _p(lse), _pi(target), B, V, float(scale), _p(d_pred), _p(dE),
-                                    _p(sq_partial), _stream()), "mtam_score32_bwd")
+                                    _p(sq_partial), 0 if sq_partial is None else
+                                    (sq_partial.numel() if n_sq is None else int(n_sq)), _stream()), "mtam_score32_bwd")
 
 
 def score16_logits(E16, P16, B, V, logits, ld):

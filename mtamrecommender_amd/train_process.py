@@ -170,8 +170,9 @@ class Train_main_process(object):
             batches = DataInput(self.train_set, self.FLAGS.train_batch_size)
             if shard is None:
                 return batches
-            from .data_parallel import shard as cut
-            return ((i, _GlobalBatch(cut(b, self.rank, self.world), len(b))) for i, b in batches)
+            from .data_parallel import keep_global_batch, shard as cut
+            return ((i, _GlobalBatch(cut(b, self.rank, self.world), len(b))) for i, b in batches
+                    if keep_global_batch(len(b), self.world))
         from .DataHandle.native_input import NativeDataInput
         random.shuffle(self._order)          # the same permutation random.shuffle(train_set) would apply
         return NativeDataInput(self._train_rs, self.FLAGS.train_batch_size, self._packer, index=self._order,
@@ -226,13 +227,20 @@ class Train_main_process(object):
                     add_summary = bool(self.global_step % self.FLAGS.display_freq == 0)
                     if self.world > 1:      # the loss is a mean over the whole batch, not over this rank's slice
                         self.model.path.global_batch = train_batch_data.global_size
-                    step_loss, merge = self.model.train(self.sess, train_batch_data, learning_rate,
-                                                        add_summary, self.global_step, epoch)
-                    self.model.train_writer.add_summary(merge, self.global_step)
-                    avg_loss = avg_loss + step_loss
+                    got = self.model.train(self.sess, train_batch_data, learning_rate,
+                                           add_summary, self.global_step, epoch)
                     self.global_step = self.global_step + 1
                     self.one_epoch_step = self.one_epoch_step + 1
-                    if self.global_step % self.FLAGS.eval_freq == 0:
+                    at_eval = self.global_step % self.FLAGS.eval_freq == 0
+                    # async_loss: `got` is the PREVIOUS step's loss (nothing on the first call); every loss is
+                    # logged exactly once under the step it belongs to, and the window average is complete
+                    # because the most recent step's is drained before it is printed
+                    for loss, merge in filter(None, (got, self.model.drain_loss() if at_eval else None)):
+                        if merge.get("loss_step") is not None:
+                            step_loss = loss
+                            self.model.train_writer.add_summary(merge, merge["loss_step"])
+                            avg_loss = avg_loss + loss
+                    if at_eval:
                         self.logger.info("Epoch step is " + str(self.one_epoch_step))
                         self.logger.info("Global step is " + str(self.global_step))
                         self.logger.info("Train_loss is " + str(avg_loss / self.FLAGS.eval_freq))
@@ -246,6 +254,11 @@ class Train_main_process(object):
                     self.logger.info(e)
                 if max_steps is not None and self.global_step >= max_steps:
                     break
+            last = self.model.drain_loss()
+            if last is not None:
+                step_loss = last[0]
+                self.model.train_writer.add_summary(last[1], last[1]["loss_step"])
+                avg_loss = avg_loss + step_loss
             self.logger.info('one epoch Cost time: %.2f' % (time.time() - epoch_start_time))
             self.logger.info("Global step is " + str(self.global_step))
             self.logger.info("Train_loss is " + str(step_loss))

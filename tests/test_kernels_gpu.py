@@ -903,6 +903,34 @@ def test_score32_lse_and_backward(ops, B, V, form):
         ops.score32_set_split_min_rows(1)
 
 
+def test_score32_rejects_buffers_sized_under_the_other_form(ops):
+    """The partial-buffer counts depend on the form (mtam_score32_set_split_min_rows is process-global state): a
+    buffer sized under one form is REJECTED when the other is in force, not overrun -- and the backward's
+    squared-norm partials must be exactly what its consumer will sum."""
+    B, V = 128, 200003
+    ops.score32_set_split_min_rows(1)
+    try:
+        n_split, n_sq_split = ops.score32_partials(B, V), ops.score32_sq_partials(V)
+        ops.score32_set_split_min_rows(0)
+        n_native, n_sq_native = ops.score32_partials(B, V), ops.score32_sq_partials(V)
+        assert n_split != n_native
+        small, big = sorted([(n_split, 1), (n_native, 0)])
+        E = torch.zeros((V, D), device="cuda")
+        P = torch.zeros((B, D), device="cuda")
+        tgt = torch.zeros(B, dtype=torch.int32, device="cuda")
+        lse, ce = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+        ops.score32_set_split_min_rows(big[1])
+        with pytest.raises(RuntimeError, match="partial buffer holds"):
+            ops.score32_lse(E, P, tgt, B, V, torch.zeros(small[0], device="cuda"), lse, ce)
+        if n_sq_split != n_sq_native:
+            ops.score32_set_split_min_rows(1)
+            with pytest.raises(RuntimeError, match="sq_partial holds"):
+                ops.score32_bwd(E, P, lse, tgt, B, V, 1.0 / B, torch.zeros((B, D), device="cuda"),
+                                torch.zeros((V, D), device="cuda"), torch.zeros(n_sq_native, device="cuda"))
+    finally:
+        ops.score32_set_split_min_rows(1)
+
+
 def _score32_case(ops, B, V, form):
     rng = np.random.default_rng(B * 3 + V)
     E = dev((rng.standard_normal((V, D)) * 0.2).astype(np.float32))

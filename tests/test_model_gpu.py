@@ -175,6 +175,30 @@ def test_checkpoint_round_trip(hip_lib, tmp_path):
         assert np.array_equal(before[k], after[k]), k
 
 
+def test_optimizer_state_is_saved_over_the_true_parameter_space(hip_lib, tmp_path):
+    """The checkpoint holds Adam's slots over [:n_total] only -- not the item pad rows or the data-parallel loss tail
+    behind them -- and restore() takes a state of that length as well as one written when the whole allocation was
+    saved (longer: its head is the state)."""
+    model, FLAGS, records = build(tmp_path, 16, 8, 1, 1)
+    p = model.path
+    model.train(model.sess, records, 1e-3)
+    st = p.optimizer_state()
+    assert st["flat_m"].numel() == p.n_total == st["flat_v"].numel() and p.n_alloc > p.n_total
+    m, v = p.flat_m.clone(), p.flat_v.clone()
+    model.save(model.sess, global_step=1)
+    model.train(model.sess, records, 1e-3)
+    p.flat_g[p.n_total:].fill_(7.0)             # (what an all-reduced loss tail leaves behind: never state)
+    model.restore(model.sess, str(tmp_path))
+    assert torch.equal(p.flat_m, m) and torch.equal(p.flat_v, v)
+    old_style = {"flat_m": torch.cat([st["flat_m"], torch.full((p.n_alloc - p.n_total,), 3.0)]),
+                 "flat_v": torch.cat([st["flat_v"], torch.full((p.n_alloc - p.n_total,), 3.0)]),
+                 "adam_state": st["adam_state"]}
+    p.load_optimizer_state(old_style)
+    assert torch.equal(p.flat_m, m) and torch.equal(p.flat_v, v)        # the tail of an old file is not state
+    with pytest.raises(ValueError):
+        p.load_optimizer_state({"flat_m": st["flat_m"][:-1], "flat_v": st["flat_v"], "adam_state": st["adam_state"]})
+
+
 @pytest.mark.parametrize("dp_mode", ["fused", "split"])
 def test_data_parallel_code_path_single_rank(hip_lib, tmp_path, dp_mode):
     """world_size = 1 over RCCL: the data-parallel step -- one graph with the all-reduce captured inside
@@ -387,6 +411,38 @@ def test_trainer_loop_runs_on_both_feeds(hip_lib, tmp_path, native):
                            counts=dict(user_count=30, item_count=120, category_count=9))
     t.train(max_steps=6)
     assert t.global_step == 6
+
+
+def test_async_loss_is_logged_once_under_its_own_step(hip_lib, tmp_path):
+    """async_loss: train() hands over the PREVIOUS step's loss together with the step it belongs to, nothing on the
+    first call, and drain_loss() the most recent one -- so a loop sees every step's loss exactly once, equal to
+    what the blocking form returns for that step (the reference's sess.run returns the loss of the step it ran,
+    Model/base_model.py:159-167)."""
+    model_a, FLAGS, records = build(tmp_path, 16, 8, 1, 1)
+    model_b, _, _ = build(tmp_path, 16, 8, 1, 1)
+    model_a.use_graph = model_b.use_graph = False     # (float atomics aside, the two models then walk the same path)
+    want = [model_a.train(model_a.sess, records, 1e-3, global_step=s)[0] for s in range(5)]
+    model_b.async_loss = True
+    seen = {}
+    for s in range(5):
+        loss, summary = model_b.train(model_b.sess, records, 1e-3, global_step=s)
+        if s == 0:
+            assert np.isnan(loss) and summary["loss_step"] is None and model_b.loss_step is None
+        else:
+            assert summary["loss_step"] == s - 1 == model_b.loss_step
+            assert summary["loss_step"] not in seen
+            seen[summary["loss_step"]] = loss
+        if s == 2:                                      # e.g. an evaluation point: the window must be complete
+            loss, summary = model_b.drain_loss()
+            assert summary["loss_step"] == 2
+            seen[2] = loss
+            assert model_b.drain_loss() is None
+    loss, summary = model_b.drain_loss()
+    seen[summary["loss_step"]] = loss
+    assert sorted(seen) == [0, 1, 2, 3, 4]
+    for s in range(5):
+        assert abs(seen[s] - want[s]) <= 2e-5 * abs(want[s]), (s, seen[s], want[s])
+    assert want[4] < want[0]
 
 
 def test_tf_named_npz_round_trip(hip_lib, tmp_path):

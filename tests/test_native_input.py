@@ -185,3 +185,35 @@ def test_sharded_iterators_partition_every_global_batch(host):
         assert np.array_equal(np.concatenate([b.index for _, b in parts]), g.index)
         want = [data_parallel.shard(list(g.index), r, world) for r in range(world)]
         assert [list(b.index) for _, b in parts] == want
+
+
+def test_a_last_global_batch_smaller_than_the_world_is_dropped_on_every_rank(host):
+    """21 records, global batch 10, 2 ranks: the last global batch has ONE record -- rank 0's slice would be empty
+    while rank 1 waits inside the gradient exchange.  Decided on the global size, so both ranks drop it: both
+    iterators yield the same number of steps and no empty batch (and so does the Python-list route)."""
+    from mtamrecommender_amd import data_parallel
+    from mtamrecommender_amd.DataHandle.get_input_data import DataInput
+    from mtamrecommender_amd.DataHandle.native_input import BatchPacker, NativeDataInput, RecordSet
+    from mtamrecommender_amd.Embedding.Behavior_embedding_time_aware_attention import \
+        Behavior_embedding_time_aware_attention
+    cat, records = _records(n=21, L=12)
+    emb = Behavior_embedding_time_aware_attention(True, cat.user_count, cat.item_count, cat.category_count, 12)
+    emb.init_placeholders()
+    rs = RecordSet.from_records(records)
+    packer = BatchPacker(12, emb)
+    world = 2
+    steps = [[(s, b.B, b.global_size) for s, b in NativeDataInput(rs, 10, packer, shard=(r, world))]
+             for r in range(world)]
+    assert [len(x) for x in steps] == [2, 2]
+    assert all(B > 0 for x in steps for _, B, _ in x)
+    assert [g for _, _, g in steps[0]] == [g for _, _, g in steps[1]] == [10, 10]
+    # one rank keeps the partial batch, as the reference does
+    assert [b.B for _, b in NativeDataInput(rs, 10, packer)] == [10, 10, 1]
+    # the list route: the same rule, stated once
+    kept = [len(b) for _, b in DataInput(records, 10) if data_parallel.keep_global_batch(len(b), world)]
+    assert kept == [10, 10]
+    # a partial batch that still gives every rank a sample stays (sizes differ by one)
+    cat, records = _records(n=23, L=12)
+    rs = RecordSet.from_records(records)
+    sizes = [[b.B for _, b in NativeDataInput(rs, 10, packer, shard=(r, world))] for r in range(world)]
+    assert sizes == [[5, 5, 1], [5, 5, 2]]

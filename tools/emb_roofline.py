@@ -1,7 +1,7 @@
 """Embedding gather / scatter-add roofline sweep (developer tool, GPU box only).
 
     python3 tools/emb_roofline.py sweep            # graph-timed us/launch over batch x catalog sizes
-    python3 tools/emb_roofline.py pmc B V [N]      # N eager launches of each kernel (run under rocprofv3 --pmc)
+    python3 tools/emb_roofline.py pmc B V [N] [dist]   # N eager launches of each kernel (run under rocprofv3 --pmc)
 
 Algorithmic bytes follow SURVEY.md 8(d): gather (3L+1)(2*D*4+4) per sequence,
 scatter-add (3L+1)(3*D*4+4) per sequence, L = 50, D = 128, fp32.
@@ -22,21 +22,14 @@ L, D = 50, 128
 
 
 def make_case(B, V, dist="zipf", seed=1234, n_cat=304, n_user=4835, tables=None):
-    rng = np.random.Generator(np.random.PCG64(seed))
-    sl = rng.integers(2, L + 1, size=B)
-    live = np.arange(L)[None, :] < sl[:, None]
-    if dist == "zipf":
-        items = np.mod(rng.zipf(1.1, size=(B, L)).astype(np.int64) - 1, V - 3)
-    else:
-        items = rng.integers(0, V - 3, size=(B, L))
-    cmap = rng.integers(0, n_cat - 3, size=V)
-    cats = cmap[items]
-    pos = np.tile(np.arange(L), (B, 1))
-    items, cats, pos = items * live, cats * live, pos * live
+    """ids from mtamrecommender_amd.data.synthetic.make_id_batch -- the generator bench.py's roofline_at_scale
+    legs use, same seeds, so the --pmc passes taken here describe those legs."""
+    from mtamrecommender_amd.data.synthetic import make_id_batch
+    ids = make_id_batch(B, L, V, n_cat, n_user, dist, seed)
     dev = "cuda"
-    t = lambda a, dt=torch.int32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
-    case = dict(B=B, V=V, item_ids=t(items), cat_ids=t(cats), pos_ids=t(pos),
-                user_ids=t(rng.integers(0, n_user, size=B)), seq_len=t(sl))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    case = dict(B=B, V=V, item_ids=t(ids["item_list"]), cat_ids=t(ids["category_list"]),
+                pos_ids=t(ids["position_list"]), user_ids=t(ids["user_id"]), seq_len=t(ids["seq_length"]))
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev).uniform_(-0.2, 0.2)
     R = B * L
     if tables is None:
@@ -48,7 +41,7 @@ def make_case(B, V, dist="zipf", seed=1234, n_cat=304, n_user=4835, tables=None)
     case.update(ic=f(R, 2 * D), pos_out=f(R, D), user_out=f(B, D), d_ic=f(R, 2 * D), d_pos=f(R, D),
                 l2=torch.zeros(ops.emb_gather_partials(B, L), device=dev),
                 sq=torch.zeros(ops.emb_scatter_partials(B, L), device=dev))
-    case["live_rows"] = int(live.sum()) * 3 + B
+    case["live_rows"] = ids["live_rows"]
     return case
 
 
@@ -115,16 +108,18 @@ def sweep():
     return out
 
 
-def pmc(B, V, n):
-    c = make_case(B, V)
+def pmc(B, V, n, dist="zipf"):
+    """n eager launches of each kernel, every launch on its own id set and buffers (as in the timed legs)."""
+    c = make_case(B, V, dist)
+    cases = [c] + [make_case(B, V, dist, seed=1234 + i, tables=c) for i in range(1, n)]
     torch.cuda.synchronize()
-    for _ in range(n):
-        gather(c)
+    for cc in cases:
+        gather(cc)
         torch.cuda.synchronize()
-    for _ in range(n):
-        scatter(c)
+    for cc in cases:
+        scatter(cc)
         torch.cuda.synchronize()
-    print(json.dumps(dict(B=B, V=V, launches=n, live_rows=c["live_rows"],
+    print(json.dumps(dict(B=B, V=V, dist=dist, launches=n, live_rows=c["live_rows"],
                           gather_alg_bytes=(3 * L + 1) * (2 * D * 4 + 4) * B,
                           scatter_alg_bytes=(3 * L + 1) * (3 * D * 4 + 4) * B)))
 
@@ -133,4 +128,5 @@ if __name__ == "__main__":
     if sys.argv[1] == "sweep":
         sweep()
     else:
-        pmc(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 10)
+        pmc(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 6,
+            sys.argv[5] if len(sys.argv) > 5 else "zipf")

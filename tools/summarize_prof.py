@@ -48,7 +48,30 @@ def pmc(fetch_csv, write_csv):
     print(json.dumps(out, indent=1))
 
 
+def pmc_scale(out_dir, cases):
+    """cases: "B512_V3709_zipf,..." -- reads OUT/pmc_fetch_<case>/ and OUT/pmc_write_<case>/ counter CSVs and
+    prints {case: {"gather": {...}, "scatter": {...}}} (the file bench.py's roofline_at_scale reads)."""
+    import glob
+    import io
+    import contextlib
+    table = collections.OrderedDict()
+    for case in cases.split(","):
+        fetch = glob.glob("%s/pmc_fetch_%s/*counter_collection.csv" % (out_dir, case))
+        write = glob.glob("%s/pmc_write_%s/*counter_collection.csv" % (out_dir, case))
+        if not fetch or not write:
+            continue
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            pmc(fetch[0], write[0])
+        d = json.loads(buf.getvalue())
+        table[case] = {("gather" if "gather" in k else "scatter"): v for k, v in d.items()}
+    print(json.dumps(table, indent=1))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "pmc_scale":
+        pmc_scale(sys.argv[2], sys.argv[3])
+        sys.exit(0)
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
