@@ -4,7 +4,10 @@ PARITY UNPINNED: the reference has no golden vectors and TensorFlow 1.14 cannot
 run here, so these fixtures come from this repo's own oracle
 (oracle/mtam_oracle.py, float64), cross-checked against oracle/numpy_ref.py when
 they are made.  They pin the oracle against regressions and travel to the GPU
-box, where the HIP path is compared with them.
+box, where the HIP path is compared with them.  Records, the padded feed, the
+variable list and the initial values are the oracle's own (oracle/records.py,
+feed_ref.py, specs.py); the GPU test rebuilds the records from the committed feed
+arrays and the weights from oracle/specs.py.
 
     python tests/golden/make_golden.py
 """
@@ -17,10 +20,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-from mtamrecommender_amd.data.synthetic import SyntheticCatalog, make_records  # noqa: E402
-from mtamrecommender_amd.Embedding.feed import pad_batch  # noqa: E402
-from mtamrecommender_amd.Model.variables import init_variables, model_specs  # noqa: E402
-from oracle import mtam_oracle as O, numpy_ref as N  # noqa: E402
+from oracle import feed_ref, mtam_oracle as O, numpy_ref as N, records as R, specs as S  # noqa: E402
 
 CASES = {
     # name: (model, B, L, D, NB, H, items, cats, users, seed)
@@ -38,15 +38,11 @@ REG = 5e-5
 
 
 def make_case(model, B, L, D, NB, H, items, cats, users, seed):
-    cat = SyntheticCatalog(items, cats, users, seed=seed)
-    records = make_records(cat, B, L, seed=seed + 1)
-    feed = pad_batch(records, L)
-    specs = model_specs(model, users, items, cats, L, D, NB)
-    arrays = init_variables(specs, seed=seed + 2)
-    rng = np.random.default_rng(seed + 3)
-    for k, v in arrays.items():                      # non-trivial biases / LN scales
-        if v.ndim == 1 or v.shape[0] == 1:
-            arrays[k] = (v + rng.normal(0, 0.05, v.shape)).astype(np.float32)
+    """Inputs, weights and the variable list all come from oracle/ (records.py, feed_ref.py, specs.py): nothing of
+    the product takes part in making a fixture.  jitter: non-trivial biases / LN scales."""
+    records = R.make_records(items, cats, users, B, L, seed=seed + 1)
+    feed = feed_ref.make_feed_dic_new(records, L)
+    arrays = S.init_arrays(S.model_vars(model, users, items, cats, L, D, NB), seed=seed + 2, jitter=0.05)
     return records, feed, arrays
 
 

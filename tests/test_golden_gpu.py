@@ -20,8 +20,16 @@ def test_hip_matches_golden(hip_lib, tmp_path, path):
     from tests.golden.make_golden import CASES, make_case
     name = os.path.splitext(os.path.basename(path))[0]
     model_name, B, L, D, NB, H, items, cats, users, seed = CASES[name]
-    records, feed, arrays = make_case(*CASES[name])
+    from oracle import records as R
     gold = np.load(path)
+    # inputs are the COMMITTED arrays (the records rebuilt from them); weights are re-drawn from the oracle's
+    # variable list and must reproduce the committed checksum
+    feed = {k[5:]: gold[k] for k in gold.files if k.startswith("feed_")}
+    records = R.records_from_feed(feed)
+    _, feed_again, arrays = make_case(*CASES[name])
+    assert all(np.array_equal(feed[k], feed_again[k]) for k in feed)
+    checksum = float(sum(np.abs(v.astype(np.float64)).sum() for v in arrays.values()))
+    assert abs(checksum - gold["weights_checksum"][0]) <= 1e-9 * checksum
     FLAGS = model_parameter().get_parameter("MTAMb1_movielen").FLAGS
     FLAGS.num_blocks, FLAGS.num_heads, FLAGS.length_of_user_history = NB, H, L
     FLAGS.checkpoint_path_dir = str(tmp_path)

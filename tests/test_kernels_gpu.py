@@ -283,8 +283,17 @@ def test_emb_scatter_add_fused_sources(ops, B, L, with_user):
 
 
 # ------------------------------------------------------------------- GRU
+# Variable names come from the oracle's own tables (oracle/family.py, oracle/specs.py), not from the product's;
+# the ROW ORDER of the packed kernel operands is the C ABI's (include/mtam_hip.h: tvec [8, D], tparams [5, L]).
+from oracle.family import CELL_SCOPE, TIME_GATE_VARS as TIME_GATE  # noqa: E402
+from oracle import specs as ORACLE_SPECS  # noqa: E402
+GRU_SCOPE = CELL_SCOPE["decay_new"]
+GRU_USED = ("_time_kernel_w1", "_time_kernel_b1", "_time_history_w1", "_time_w1", "_time_b1", "_time_kernel_w2",
+            "_time_w12", "_time_b12")            # mtam_tagru_fwd's tvec rows, include/mtam_hip.h
+assert sorted(GRU_USED) == sorted(n for n, _ in ORACLE_SPECS.DECAY_NEW_LIVE)
+
+
 def _gru_weights(rng):
-    from mtamrecommender_amd.Model.variables import GRU_SCOPE, GRU_USED
     w = {GRU_SCOPE + "gates/kernel": rng.uniform(-0.1, 0.1, (2 * D, 2 * D)),
          GRU_SCOPE + "gates/bias": rng.uniform(0.5, 1.5, 2 * D),
          GRU_SCOPE + "candidate/kernel": rng.uniform(-0.1, 0.1, (2 * D, D)),
@@ -296,7 +305,6 @@ def _gru_weights(rng):
 
 
 def _gru_device_args(w):
-    from mtamrecommender_amd.Model.variables import GRU_SCOPE, GRU_USED
     Wg, Wc = w[GRU_SCOPE + "gates/kernel"], w[GRU_SCOPE + "candidate/kernel"]
     Wx = np.concatenate([Wg[:D], Wc[:D]], axis=1)                 # [D, 3D]
     bx = np.concatenate([w[GRU_SCOPE + "gates/bias"], w[GRU_SCOPE + "candidate/bias"]])
@@ -337,7 +345,6 @@ def test_tagru_fwd_bwd(ops, B, L):
     d_xt = torch.full((R, D), 3.0, device="cuda")
     d_tv = torch.zeros((B, 8, D), device="cuda")
     ops.tagru_bwd(dev(d_short), xd, tld, sld, dev(whg), dev(whc), dev(tvec), save, B, L, d_xproj, rh, d_xt, d_tv)
-    from mtamrecommender_amd.Model.variables import GRU_SCOPE, GRU_USED
     # gradients of the parameters the kernel owns directly
     got_tv = d_tv.cpu().numpy().astype(np.float64).sum(0)
     for i, n in enumerate(GRU_USED):
@@ -362,7 +369,6 @@ def test_tagru_fwd_bwd(ops, B, L):
 # -------------------------------------------------------------- attention
 def _attn_case(rng, B, L, H):
     scope, inner = "blk/", "vanilla_attention"
-    from mtamrecommender_amd.Model.variables import TIME_GATE
     w = {}
     for layer in ("dense", "dense_1", "dense_2"):
         w[scope + layer + "/kernel"] = rng.uniform(-0.15, 0.15, (D, D))
@@ -387,7 +393,6 @@ def _attn_case(rng, B, L, H):
 @pytest.mark.parametrize("B,L,H", [(4, 6, 1), (9, 50, 2), (128, 50, 1), (8, 200, 8)])
 def test_ta_attn_decode_fwd_bwd(ops, B, L, H):
     import oracle.mtam_oracle as O
-    from mtamrecommender_amd.Model.variables import TIME_GATE
     rng = np.random.default_rng(B * 3 + L + H)
     scope, inner, w, q, x, sl, tq, tk = _attn_case(rng, B, L, H)
     s = scope + inner + "/"

@@ -50,6 +50,11 @@ def build(tmp_path, B, L, NB, H, items=300, cats=17, users=40, seed=5, id_dist="
         if v.ndim == 1 or v.shape[0] == 1:
             arrays[k] = (v + rng.normal(0, 0.05, v.shape)).astype(np.float32)
     model.set_variables(arrays)
+    # the product's variable set against the ORACLE's own list (oracle/specs.py): same names, same shapes
+    from oracle import specs as S
+    spec_model = "PISTRec" if model_name in ("PISTRec", "Time_Aware_Self_Attention_Model") else model_name
+    want = {v.name: tuple(v.shape) for v in S.model_vars(spec_model, users, items, cats, L, 128, NB)}
+    assert {k: tuple(v.shape) for k, v in arrays.items()} == want
     records = make_records(cat, B, L, seed=seed + 1, id_dist=id_dist)
     return model, FLAGS, records
 
@@ -411,6 +416,35 @@ def test_trainer_loop_runs_on_both_feeds(hip_lib, tmp_path, native):
                            counts=dict(user_count=30, item_count=120, category_count=9))
     t.train(max_steps=6)
     assert t.global_step == 6
+
+
+@pytest.mark.parametrize("model_name,NB", [("MTAM", 2), ("MTAM_via_T_GRU", 1), ("PISTRec", 2)])
+def test_dead_variables_get_no_gradient_and_no_update(hip_lib, tmp_path, model_name, NB):
+    """The variables the reference declares and never reads (oracle/specs.py ``live=False``: 6 GRU vectors,
+    time_output_w3 per block) receive a None gradient in TF: clip_by_global_norm and
+    apply_gradients skip them.  Here: they are not part of the gradient the step produces, the clip norm equals the
+    norm over the LIVE variables, and three optimizer steps leave them bit-identical -- while every live variable
+    that the oracle gives a non-zero gradient moves."""
+    import oracle.mtam_oracle as O
+    from oracle import specs as S
+    model, FLAGS, records = build(tmp_path, 6, 8, NB, 1, model_name=model_name)
+    vars_ = S.model_vars(model_name, 40, 300, 17, 8, 128, NB)
+    dead, live = S.dead_names(vars_), S.live_names(vars_)
+    assert len(dead) == (NB if model_name == "PISTRec" else 6 + NB)
+    before = {k: v.copy() for k, v in model.get_variables().items()}
+    feed = model.embedding.make_feed_dic_new(records)
+    out, grads, slot_sq = O.loss_and_grads(model_name, before, feed, 1, NB, FLAGS.regulation_rate, torch.float64)
+    assert sorted(k for k in dead) == sorted(k for k, g in grads.items() if g is None and k in dead)
+    for _ in range(3):
+        model.train(model.sess, records, 1e-3)
+    got = model.path.grads_tf()
+    assert not (set(got) & set(dead)), "a dead variable was given a gradient"
+    after = model.get_variables()
+    for k in dead:
+        assert np.array_equal(before[k], after[k]), k
+    for k in live:
+        if grads.get(k) is not None and np.abs(grads[k]).max() > 0:
+            assert not np.array_equal(before[k], after[k]), k
 
 
 def test_async_loss_is_logged_once_under_its_own_step(hip_lib, tmp_path):
