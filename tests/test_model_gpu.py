@@ -460,7 +460,7 @@ def test_async_loss_is_logged_once_under_its_own_step(hip_lib, tmp_path):
     seen = {}
     for s in range(5):
         loss, summary = model_b.train(model_b.sess, records, 1e-3, global_step=s)
-        if s == 0:
+        if s in (0, 3):                                 # nothing finished yet / already handed over by the drain
             assert np.isnan(loss) and summary["loss_step"] is None and model_b.loss_step is None
         else:
             assert summary["loss_step"] == s - 1 == model_b.loss_step
