@@ -85,23 +85,11 @@ def time_kernel(fns, torch, reps=50, replays=20):
 
 
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE in separate runs, gfx950 read correction applied: tools/summarize_prof.py pmc).  PMC
-    counters cannot be collected inside this process, so the figure comes from the newest
-    profiles/r*_pmc_emb_*.json (kernel names there carry their C++ decoration, e.g.
-    "void emb_gather_kernel<false>": matched by substring); None when no such file travels with the tree."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_emb_*.json")))
-    if not files:
-        return None
-    try:
-        table = json.load(open(files[-1]))
-        for name, row in table.items():
-            if kernel in name:
-                return float(row["traffic_bytes"])
-    except (KeyError, ValueError, OSError):
-        pass
-    return None
+    """HBM-side bytes per launch of `kernel` at the headline size (128 sequences, ml-1m tables) from the committed
+    rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 read correction applied:
+    tools/summarize_prof.py).  PMC counters cannot be collected inside this process, so the figure comes from the
+    newest profiles/r*_pmc_emb_scale*.json (case "B128_V3709_zipf"); None when no such file travels with the tree."""
+    return pmc_scale_traffic("B128_V3709_zipf", kernel.split("_")[1])
 
 
 SCALE_LEGS = [(512, "run", "zipf"), (2048, "run", "zipf"), (512, "1m", "zipf"), (2048, "1m", "zipf"),

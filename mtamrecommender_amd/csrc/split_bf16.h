@@ -62,4 +62,37 @@ __device__ __forceinline__ bf16x8 lds_tr8(const unsigned char *lo, const unsigne
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// ---- B-operand images of a row-major fp32 weight matrix W [K, N] (K a multiple of 8), kept beside the fp32 master:
+// three bf16 terms (W = W1 + W2 + W3), each stored [K / 8][N][8] -- the 8 consecutive k a lane of
+// v_mfma_f32_32x32x16_bf16 supplies for its column sit in one 16-byte piece, and the 32 lanes of a half wave read
+// 512 contiguous bytes.  Term t starts at t * K * N.  Written by the optimizer launch that updates W
+// (csrc/optim.hip) or by mtam_split_weight_images; read by csrc/seq_chain.hip.
+__host__ __device__ inline size_t wimg_elems(int K, int N) { return (size_t)3 * K * N; }
+__host__ __device__ inline size_t wimg_off(int k, int n, int N) { return ((size_t)(k >> 3) * N + n) * 8 + (k & 7); }
+__device__ __forceinline__ void wimg_store(uint16_t *img, int K, int N, int k, int n, float w) {
+  __bf16 a, b, c;
+  split3(w, a, b, c);
+  const size_t o = wimg_off(k, n, N), term = (size_t)K * N;
+  img[o] = __builtin_bit_cast(uint16_t, a);
+  img[term + o] = __builtin_bit_cast(uint16_t, b);
+  img[2 * term + o] = __builtin_bit_cast(uint16_t, c);
+}
+// the six products, two independent accumulator chains interleaved (a dependent MFMA waits for its predecessor's
+// last pass; two chains keep the pipe issuing back to back)
+__device__ __forceinline__ void mfma6x2(const Tri &a0, const Tri &b0, f32x16 &c0, const Tri &a1, const Tri &b1,
+                                        f32x16 &c1) {
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.t[2], b0.t[0], c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.t[2], b1.t[0], c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.t[1], b0.t[1], c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.t[1], b1.t[1], c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.t[0], b0.t[2], c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.t[0], b1.t[2], c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.t[1], b0.t[0], c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.t[1], b1.t[0], c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.t[0], b0.t[1], c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.t[0], b1.t[1], c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.t[0], b0.t[0], c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.t[0], b1.t[0], c1, 0, 0, 0);
+}
+
 }  // namespace split_bf16
