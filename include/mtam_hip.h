@@ -446,7 +446,35 @@ int mtam_score32_bwd(const float *E, const float *pred, const float *lse, const 
  * every output 16-byte aligned.  A workgroup owns a 32-row stripe; x stays on the CU between the products. */
 int mtam_seq_chain_fwd(const float *ic, const float *W4, const float *pos, int R, const float *Wkv,
                        const float *bkv, int n_kv, const float *Wx, const float *bx, int n_x, float *zr, float *x,
-                       float *kv, float *xproj, void *stream);
+                       float *kv, float *xproj, const uint16_t *w_images, void *stream);
+/* w_images (both chain entry points): NULL = the three products on v_mfma_f32_32x32x2_f32.  Otherwise the bf16
+ * operand images of W4, Wkv and Wx -- one buffer of mtam_seq_chain_images_elems(n_kv, n_x) bf16 values,
+ * [W4 | Wkv | Wx] (mtam_seq_chain_image_offset(which, n_kv) = where matrix `which` = 0, 1, 2 starts), each matrix as
+ * three images (W = W1 + W2 + W3 exactly, bf16 each; image t at t K N) in the order [K / 8][N][8] -- and every
+ * product runs as six v_mfma_f32_32x32x16_bf16 terms with fp32 accumulation: fp32-equivalent (the dropped terms
+ * are <= 2^-23 |a b|), 448 fp32 matrix instructions of 64 cycles per wave become 336 of 32.  The images are
+ * written by the optimizer launch that updates the weights (mtam_adam_images) -- no per-step prepare launch --
+ * or, whenever the weights change any other way, by mtam_split_weight_images (one launch per matrix). */
+size_t mtam_seq_chain_images_elems(int n_kv, int n_x);
+size_t mtam_seq_chain_image_offset(int which, int n_kv);
+int mtam_split_weight_images(const float *W, int K, int N, uint16_t *images, void *stream);
+/* The backward's sequence-side chain in one launch (the mirror of mtam_seq_chain_fwd; replaces the dual-source
+ * mtam_gemm_f32_dual(ACCUM2_MASK) and the d[item | category] GEMM; tf.gradients of
+ * Embedding/Behavior_embedding_time_aware_attention.py:95-103, Model/Modules/time_aware_attention.py:251-253,
+ * Model/Modules/time_aware_rnn.py:243-256):
+ *   d_x  [R, 128] in/out: += d_xproj [R, n_x] . Wx^T + d_kv [R, n_kv] . Wkv^T + d_xt [R, 128]
+ *   d_z  [R, 128] out   : d_x where zr > 0
+ *   d_ic [R, 256] out   : d_z . W4^T
+ * n_x, n_kv multiples of 128, n_x + n_kv <= mtam_seq_chain_bwd_max_k() (n_kv = 0, d_kv = NULL: no key / value source;
+ * wider models keep the two GEMM launches).  A workgroup owns a 32-row stripe; d_z
+ * stays on the CU between the two products; split-bf16 products (fp32-equivalent).  w_images_r: the bf16 images of
+ * the three matrices' TRANSPOSES (the B operands of products with W^T), one buffer laid out like w_images
+ * ([W4 | Wkv | Wx], the same offsets): matrix W [K, N] as three terms (term t at t K N), element W[k][n] at
+ * ((n >> 3) K + k) 8 + (n & 7), N a multiple of 8.  Written by mtam_adam_images (images_r) or mtam_split_weight_rows. */
+int mtam_split_weight_rows(const float *W, int K, int N, uint16_t *images_r, void *stream);
+int mtam_seq_chain_bwd_max_k(void); /* largest n_x + n_kv the staged stripe holds (640: one decoder block) */
+int mtam_seq_chain_bwd(const float *d_xproj, int n_x, const float *d_kv, int n_kv, const float *d_xt, const float *zr,
+                       int R, float *d_x, float *d_z, float *d_ic, const uint16_t *w_images_r, void *stream);
 /* The same launch with the four embedding lookups folded in (mtam_emb_gather_fwd + mtam_seq_chain_fwd as ONE
  * kernel: SURVEY.md 2.1 K1 + K2): a workgroup gathers its stripe's [item | category] rows straight into the LDS
  * operand of the first product and its position rows into the epilogue registers; the rows are never read back
@@ -465,7 +493,7 @@ int mtam_seq_chain_gather_fwd(const float *item_table, int item_rows, const floa
                               const float *Wkv, const float *bkv, int n_kv, const float *Wx, const float *bx,
                               int n_x, float *ic_out, float *user_out, float *l2_partial, int n_l2, float *zr,
                               float *x, float *kv, float *xproj, float *clear_a, size_t n_clear_a, float *clear_b,
-                              size_t n_clear_b, void *stream);
+                              size_t n_clear_b, const uint16_t *w_images, void *stream);
 
 /* ------------------------------------------------------------------ top-K
  * tf.nn.top_k (Model/base_model.py:196-200): for every row the k largest
@@ -543,6 +571,22 @@ int mtam_adam(float *p, float *m, float *v, const float *g, size_t n, const floa
 int mtam_adam_bf16copy(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
                        const float *hyper, size_t sparse_begin, uint16_t *copy16, size_t copy_begin,
                        void *stream);
+/* mtam_adam (copy16 == NULL) / mtam_adam_bf16copy that ALSO re-writes the bf16 operand images of up to
+ * MTAM_MAX_WEIGHT_IMAGES weight matrices lying inside [0, n) -- the B operands of mtam_seq_chain_*'s split-bf16
+ * products (see there for the layout) -- from the values it has just updated: the forward of the next step finds
+ * its weights already split and laid out as MFMA fragments (Embedding/...attention.py:95-103 dense4emb,
+ * time_aware_attention.py:251-253 K / V, time_aware_rnn.py:243-256 input halves).  begin: first element of the
+ * row-major [K, N] matrix in the flat space (multiple of 4; K multiple of 8, N of 4). */
+#define MTAM_MAX_WEIGHT_IMAGES 4
+typedef struct {
+  size_t begin;
+  int K, N;
+  uint16_t *images;   /* [K / 8][N][8] per term: the forward's B fragments (mtam_seq_chain_fwd) */
+  uint16_t *images_r; /* the same layout of W^T: the backward's (mtam_seq_chain_bwd); may be NULL */
+} MtamWeightImages;
+int mtam_adam_images(float *p, float *m, float *v, const float *g, size_t n, const float *scale, const float *hyper,
+                     size_t sparse_begin, uint16_t *copy16, size_t copy_begin, const MtamWeightImages *w, int n_w,
+                     void *stream);
 
 /* The other choices of base_model.init_optimizer (Model/base_model.py:71-80):
  * kind 0 GradientDescentOptimizer, 1 AdadeltaOptimizer (rho 0.95, eps 1e-8; slot1 = accum,

@@ -66,7 +66,7 @@ class MTAM(MTAMRec_model):
             else:
                 raise KeyError(k)
         p.params.copy_(torch.from_numpy(p.layout.pack(dense)))
-        p.refresh_item16()
+        p.refresh_derived()
 
     def get_variables(self):
         out = dict(self.path.dense_tf())

@@ -152,7 +152,7 @@ class base_model(object):
             if variable_list is None or k in variable_list:
                 dense[k] = v.numpy()
         p.params.copy_(torch.from_numpy(p.layout.pack(dense)))
-        p.refresh_item16()
+        p.refresh_derived()
         if variable_list is None and "adam" in state:
             p.load_optimizer_state(state["adam"])
         self.logger.info('model restored from %s' % path)

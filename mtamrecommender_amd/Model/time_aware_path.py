@@ -268,6 +268,8 @@ class TimeAwarePath(object):
             self.nb_item = ops.score16_sq_partials(self.item_rows)
             self.item16 = torch.empty((self.item_rows, D), dtype=torch.bfloat16, device=dev)
             self.refresh_item16()
+        self._init_weight_images()
+        self.refresh_weight_images()
         self.nb_all = max(ops.sqnorm_blocks(self.n_total), self.nb_dense + self.nb_item)
         self.scale = z(2)
         self.ticket = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -326,6 +328,43 @@ class TimeAwarePath(object):
         """bf16 scoring copy of the item table <- fp32 master (after every update of the table)."""
         if self.item16 is not None:
             ops.f32_to_bf16(self.tables["item"].view(-1), self.item16.view(-1))
+
+    def _init_weight_images(self):
+        """bf16 operand images of dense4emb/w, kv/w and gru/wx for the forward's fused projection kernel
+        (csrc/seq_chain.hip, split-bf16 products): one buffer [W4 | Wkv | Wx], re-written by the Adam launch that
+        updates the weights (``mtam_adam_images``) and by ``refresh_weight_images`` whenever they change any other
+        way.  MTAM_SEQ_CHAIN_X3=0 keeps the products on the fp32 MFMA."""
+        self.wimg, self.wimg_r, self.wimg_descs, self._wimg_parts = None, None, None, []
+        segs = self.layout.segments
+        if "gru/wx" not in segs or self.cfg["gru"] == "seqrec" or os.environ.get("MTAM_SEQ_CHAIN_X3", "1") == "0":
+            return
+        kv_from_x = self.cfg["attention"] and self.cfg["keys"] == "x"
+        n_kv = segs["kv/w"].shape[1] if kv_from_x else 0
+        n_x = segs["gru/wx"].shape[1]
+        n_img = ops.seq_chain_images_elems(n_kv, n_x)
+        # ... and the images of the same three matrices' TRANSPOSES behind them, same order and offsets: the B operands
+        # of the backward's stripe kernel (mtam_seq_chain_bwd multiplies by W^T)
+        both = torch.zeros(2 * n_img, dtype=torch.bfloat16, device=self.device)
+        self.wimg, self.wimg_r = both[:n_img], both[n_img:]
+        self.wimg_n_kv = n_kv
+        names = ["dense4emb/w"] + (["kv/w"] if kv_from_x else []) + ["gru/wx"]
+        which = {"dense4emb/w": 0, "kv/w": 1, "gru/wx": 2}
+        for name in names:
+            K, N = segs[name].shape
+            o = ops.seq_chain_image_offset(which[name], n_kv)
+            self._wimg_parts.append((name, segs[name].offset, K, N, self.wimg[o:], self.wimg_r[o:]))
+        self.wimg_descs = ops.weight_image_descs([part[1:] for part in self._wimg_parts])
+
+    def refresh_weight_images(self):
+        for name, _, _, _, img, img_r in self._wimg_parts:
+            ops.split_weight_images(self.seg(name), img)
+            ops.split_weight_rows(self.seg(name), img_r)
+
+    def refresh_derived(self):
+        """Everything kept beside the fp32 parameters and derived from them: call after ANY change of
+        ``flat_p`` that did not come from this path's own optimizer launch."""
+        self.refresh_item16()
+        self.refresh_weight_images()
 
     # ----------------------------------------------------------------- scoring (base_model.output)
     def score_forward(self, bt, training):
@@ -394,7 +433,8 @@ class TimeAwarePath(object):
                                      self.seg("dense4emb/w"),
                                      self.seg("kv/w") if kv_from_x else None, self.seg("kv/b") if kv_from_x else None,
                                      self.seg("gru/wx"), self.seg("gru/bx"), bt.ic if training else None, bt.user,
-                                     bt.l2_fused, bt.zr, bt.x, bt.kv if kv_from_x else None, bt.xproj, clear=clear)
+                                     bt.l2_fused, bt.zr, bt.x, bt.kv if kv_from_x else None, bt.xproj, clear=clear,
+                                     w_images=self.wimg)
             bt.l2_live = bt.l2_fused          # 4 sums per 32-row stripe: what the loss reduction has to read
         else:
             ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
@@ -407,7 +447,7 @@ class TimeAwarePath(object):
             ops.seq_chain_fwd(bt.ic, self.seg("dense4emb/w"), bt.pos, R,
                               self.seg("kv/w") if kv_from_x else None, self.seg("kv/b") if kv_from_x else None,
                               self.seg("gru/wx"), self.seg("gru/bx"), bt.zr, bt.x, bt.kv if kv_from_x else None,
-                              bt.xproj)
+                              bt.xproj, w_images=self.wimg)
         else:
             ops.gemm(bt.ic, self.seg("dense4emb/w"), bt.x, epilogue=ops.EPI_RELU_ADD, aux_in=bt.pos, aux_out=bt.zr)
             if kv_from_x:
@@ -551,18 +591,27 @@ class TimeAwarePath(object):
         # (members without a decoder leave it untouched: cleared here)
         if not cfg["attention"]:
             bt.d_x.zero_()
-        if cfg["attention"] and cfg["keys"] == "x":
-            ops.gemm_dual(bt.d_xproj, self.seg("gru/wx"), bt.d_kv, self.seg("kv/w"), bt.d_x, trans_b=True,
-                          epilogue=ops.EPI_ACCUM2_MASK, bias=bt.d_xt, aux_in=bt.zr, aux_out=bt.d_z)
-        else:
-            ops.gemm(bt.d_xproj, self.seg("gru/wx"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM2_MASK,
-                     bias=bt.d_xt, aux_in=bt.zr, aux_out=bt.d_z)
         # MTAM_FUSED_SCATTER=1: d[item | category] = d_z . W4^T is formed inside the scatter-add, chunk by chunk (no
         # [R, 2D] round trip, one launch less).  Measured at B=128, L=50: 0.2859 ms per step against 0.2781 with the
         # separate 9 us GEMM -- a chunk's 64 dependent fp32 MFMAs and two operand round trips lengthen the 100
         # item / category workgroups of a launch that is latency-bound already -- so the GEMM stays the default
         fused_scatter = os.environ.get("MTAM_FUSED_SCATTER", "0") == "1"
-        if not fused_scatter:
+        kv_src = cfg["attention"] and cfg["keys"] == "x"
+        # the whole chain in ONE stripe kernel (d_z never leaves the CU between the two products; split-bf16 products
+        # on the images of the weights' transposes): MTAM_SEQ_CHAIN_BWD=0 keeps the two GEMM launches
+        stripe = (self.wimg_r is not None and not fused_scatter and (self.wimg_n_kv > 0) == bool(kv_src)
+                  and bt.xw * D + self.wimg_n_kv <= ops.seq_chain_bwd_max_k()
+                  and os.environ.get("MTAM_SEQ_CHAIN_BWD", "1") != "0")
+        if stripe:
+            ops.seq_chain_bwd(bt.d_xproj, bt.d_kv if kv_src else None, bt.d_xt, bt.zr, R, bt.d_x, bt.d_z, bt.d_ic,
+                              self.wimg_r)
+        elif kv_src:
+            ops.gemm_dual(bt.d_xproj, self.seg("gru/wx"), bt.d_kv, self.seg("kv/w"), bt.d_x, trans_b=True,
+                          epilogue=ops.EPI_ACCUM2_MASK, bias=bt.d_xt, aux_in=bt.zr, aux_out=bt.d_z)
+        else:
+            ops.gemm(bt.d_xproj, self.seg("gru/wx"), bt.d_x, trans_b=True, epilogue=ops.EPI_ACCUM2_MASK,
+                     bias=bt.d_xt, aux_in=bt.zr, aux_out=bt.d_z)
+        if not fused_scatter and not stripe:
             ops.gemm(bt.d_z, self.seg("dense4emb/w"), bt.d_ic, trans_b=True)
         problems.append(prob(bt.ic, 2 * D, bt.d_z, D, "dense4emb/w", 2 * D, D, R, sr))
         # every weight gradient and every bias-like gradient in ONE launch (more when a group overflows)
@@ -596,19 +645,24 @@ class TimeAwarePath(object):
         ops.sqnorm_clip_scale(self.flat_g, n_g, part, 0, n, self.clip, self.scale, bt.feed["lr"],
                               self.adam_state, self.ticket, bt.l2_live, bt.l2_live.numel(), bt.ce, bt.B,
                               self.reg, 1.0 / gb, None if self.loss_in_tail else bt.loss)
-        if self.optimizer == "adam" and self.item16 is not None:
-            # the bf16 scoring copy of the item table is refreshed by the same launch
-            ops.adam_bf16copy(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,
-                              self.adam_state, self.n_dense, self.item16, self.tab_off["item"])
-            return
         if self.optimizer == "adam":
-            ops.adam(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,
-                     self.adam_state, self.n_dense)
-        else:
-            # sparse (row-skipping) region: category, position, user; the item gradient has every row
-            ops.opt_update(self.optimizer, self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total,
-                           self.scale, bt.feed["lr"], self.n_dense, self.tab_off["item"])
-        self.refresh_item16()
+            # the bf16 scoring copy of the item table (if any) and the bf16 operand images of the forward's fused
+            # projection weights (if any) are re-written by the same launch
+            if self.wimg_descs is not None:
+                ops.adam_images(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,
+                                self.adam_state, self.n_dense, self.wimg_descs, copy16=self.item16,
+                                copy_begin=self.tab_off["item"])
+            elif self.item16 is not None:
+                ops.adam_bf16copy(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,
+                                  self.adam_state, self.n_dense, self.item16, self.tab_off["item"])
+            else:
+                ops.adam(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, self.scale,
+                         self.adam_state, self.n_dense)
+            return
+        # sparse (row-skipping) region: category, position, user; the item gradient has every row
+        ops.opt_update(self.optimizer, self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total,
+                       self.scale, bt.feed["lr"], self.n_dense, self.tab_off["item"])
+        self.refresh_derived()
 
     def forward_backward_kernels(self, bt):
         self.forward(bt, training=True)

@@ -44,7 +44,13 @@ SIGNATURES = {
     "mtam_seq_chain_gather_partials": (c_int, [c_int, c_int]),
     "mtam_seq_chain_gather_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
                                           P, P, P, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P, P, c_size_t, P,
-                                          c_size_t, P]),
+                                          c_size_t, P, P]),
+    "mtam_seq_chain_images_elems": (c_size_t, [c_int, c_int]),
+    "mtam_seq_chain_image_offset": (c_size_t, [c_int, c_int]),
+    "mtam_split_weight_images": (c_int, [P, c_int, c_int, P, P]),
+    "mtam_split_weight_rows": (c_int, [P, c_int, c_int, P, P]),
+    "mtam_seq_chain_bwd_max_k": (c_int, []),
+    "mtam_seq_chain_bwd": (c_int, [P, c_int, P, c_int, P, P, c_int, P, P, P, P, P]),
     "mtam_tagru_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "mtam_tagru_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
     "mtam_tagru_seqrec_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),
@@ -83,7 +89,7 @@ SIGNATURES = {
     "mtam_score16_sq_partials": (c_int, [c_int]),
     "mtam_score16_lse": (c_int, [P, P, P, c_int, c_int, P, P, P, P]),
     "mtam_score16_bwd": (c_int, [P, P, P, P, c_int, c_int, c_float, P, P, P, P]),
-    "mtam_seq_chain_fwd": (c_int, [P, P, P, c_int, P, P, c_int, P, P, c_int, P, P, P, P, P]),
+    "mtam_seq_chain_fwd": (c_int, [P, P, P, c_int, P, P, c_int, P, P, c_int, P, P, P, P, P, P]),
     "mtam_score32_set_split_min_rows": (None, [ctypes.c_long]),
     "mtam_score32_partials": (c_int, [c_int, c_int]),
     "mtam_score32_sq_partials": (c_int, [c_int]),
@@ -98,6 +104,7 @@ SIGNATURES = {
     "mtam_adam_block": (c_int, []),
     "mtam_adam": (c_int, [P, P, P, P, c_size_t, P, P, c_size_t, P]),
     "mtam_adam_bf16copy": (c_int, [P, P, P, P, c_size_t, P, P, c_size_t, P, c_size_t, P]),
+    "mtam_adam_images": (c_int, [P, P, P, P, c_size_t, P, P, c_size_t, P, c_size_t, P, c_int, P]),
     "mtam_opt_update": (c_int, [c_int, P, P, P, P, c_size_t, P, P, c_size_t, c_size_t, P]),
     "mtam_gemm_tn_atomic_grouped": (c_int, [c_int, P, P]),
     "mtam_colsum_atomic_multi": (c_int, [c_int, P, P]),
@@ -109,6 +116,11 @@ SIGNATURES = {
 class GemmDesc(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p),
                 ("ldc", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("split_k", c_int)]
+
+
+class WeightImages(ctypes.Structure):
+    """MtamWeightImages (include/mtam_hip.h): one weight matrix of the flat space and where its bf16 images go."""
+    _fields_ = [("begin", c_size_t), ("K", c_int), ("N", c_int), ("images", c_void_p), ("images_r", c_void_p)]
 
 
 class ColsumJob(ctypes.Structure):

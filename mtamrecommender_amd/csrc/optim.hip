@@ -4,6 +4,7 @@
 // All three kernels are HBM-bound streams: 16 B per lane, grid-stride-free
 // (one 4096-float block per workgroup) so that V x D tables fill the chip.
 #include "common.h"
+#include "split_bf16.h"
 #include <stdlib.h>
 
 namespace {
@@ -225,12 +226,33 @@ __global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restric
 // COPY: elements at or after copy_begin (the item table) are also written, rounded to nearest even, to the
 // bf16 scoring copy (csrc/score16.hip) -- 2 more bytes per element instead of a separate 6-byte pass.
 typedef __bf16 adam_bf16x4 __attribute__((ext_vector_type(4)));
+// Weight matrices whose bf16 operand images (csrc/split_bf16.h, wimg_off) are re-written by the launch that updates
+// them: the forward's fused projection kernel and the backward's stripe kernel (csrc/seq_chain.hip) read their B
+// operands already split and laid out as MFMA fragments, and no per-step prepare launch exists.  By value: at most
+// MTAM_MAX_WEIGHT_IMAGES matrices.
+// The elements of such a matrix are updated by EXTRA workgroups appended to the grid (blockIdx >= n_linear), one
+// thread per 4 rows x 4 columns: its reads and writes of p / m / v / g are 16-byte pieces coalesced over the lanes,
+// it splits the updated values and stores them as 8-byte half pieces of the forward's images (4 of the 8
+// consecutive k of a column) and 8-byte half pieces of the transpose's images.  The linear workgroups skip those
+// elements.  Measured (launch at ml-1m sizes, 8.4 us without images): the linear threads writing their four
+// elements' twelve 2-byte image entries themselves -- 48 scattered stores per thread in 28 of the 330 workgroups --
+// 13.6 us; 8 x 4 elements per image thread 11.2; 4 x 4 (as many loads as a linear thread) 9.8-10.3; the image
+// workgroups at the HEAD of the grid instead of its tail 11.3.
+struct AdamImages {
+  int n;
+  unsigned n_linear;                          // workgroups of the linear sweep
+  unsigned first_block[MTAM_MAX_WEIGHT_IMAGES + 1];   // image workgroups of matrix j: [first_block[j], first_block[j + 1])
+  size_t begin[MTAM_MAX_WEIGHT_IMAGES], end[MTAM_MAX_WEIGHT_IMAGES];
+  int K[MTAM_MAX_WEIGHT_IMAGES], N[MTAM_MAX_WEIGHT_IMAGES];
+  uint16_t *img[MTAM_MAX_WEIGHT_IMAGES], *img_r[MTAM_MAX_WEIGHT_IMAGES];
+};
 template <bool COPY, bool NT>
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m,
                                                    float *__restrict__ v, const float *__restrict__ g, size_t n,
                                                    const float *__restrict__ scale,
                                                    const float *__restrict__ hyper, size_t sparse_begin,
-                                                   uint16_t *__restrict__ copy16, size_t copy_begin) {
+                                                   uint16_t *__restrict__ copy16, size_t copy_begin,
+                                                   AdamImages wi) {
   const float sc = scale[0];
   const float lr_t = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
@@ -238,20 +260,89 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
   // elements at or after sparse_begin are table rows (IndexedSlices update form); a block never
   // straddles the boundary because sparse_begin is a multiple of the block size or 0 / n.
   const bool sparse_form = base >= sparse_begin;
-  auto step = [&](float &pp, float &mm, float &vv, float gg) {
-    gg *= sc;
-    if (sparse_form) {
-      mm = mm * b1 + gg * omb1;
-      vv = vv * b2 + (gg * gg) * omb2;
+  // Every product-sum is an EXPLICIT fma and contraction is off for the rest: the same element must come out bit
+  // for bit whichever code path of this kernel updates it (linear sweep, image role), so nothing is left to the
+  // compiler's contraction choices (__fmul_rn is a plain product in HIP: it does not stop a later fusion).
+  auto step_form = [&](float &pp, float &mm, float &vv, float gg, bool sparse) {
+#pragma clang fp contract(off)
+    gg = gg * sc;
+    if (sparse) {
+      const float t1 = gg * omb1, t2 = (gg * gg) * omb2;
+      mm = fmaf(mm, b1, t1);
+      vv = fmaf(vv, b2, t2);
     } else {
-      mm = mm + (gg - mm) * omb1;
-      vv = vv + (gg * gg - vv) * omb2;
+      const float d1 = gg - mm;
+      mm = fmaf(d1, omb1, mm);
+      const float d2 = fmaf(gg, gg, -vv);
+      vv = fmaf(d2, omb2, vv);
     }
-    pp = pp - (lr_t * mm) / (sqrtf(vv) + eps);
+    const float num = lr_t * mm, den = sqrtf(vv) + eps;
+    pp = pp - num / den;
   };
+  auto step = [&](float &pp, float &mm, float &vv, float gg) { step_form(pp, mm, vv, gg, sparse_form); };
+  if (wi.n && blockIdx.x >= wi.n_linear) {
+    // ---- image role (dense variables: the non-sparse update form): 4 rows x 4 columns of the matrix per thread
+    typedef float adam_f4 __attribute__((ext_vector_type(4)));
+    int j = 0;
+    while (j + 1 < wi.n && blockIdx.x >= wi.n_linear + wi.first_block[j + 1]) ++j;
+    const int K = wi.K[j], N = wi.N[j], n4 = N / 4;
+    const size_t unit = (size_t)(blockIdx.x - wi.n_linear - wi.first_block[j]) * 256 + threadIdx.x;
+    if (unit >= (size_t)(K / 4) * n4) return;
+    const int g4 = (int)(unit / n4), col = (int)(unit % n4) * 4;        // rows 4 g4 .. 4 g4 + 4
+    const size_t e0 = wi.begin[j] + (size_t)g4 * 4 * N + col;
+    adam_f4 pe[4], me[4], ve[4], ge[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t e = e0 + (size_t)i * N;
+      pe[i] = *reinterpret_cast<const adam_f4 *>(p + e); me[i] = *reinterpret_cast<const adam_f4 *>(m + e);
+      ve[i] = *reinterpret_cast<const adam_f4 *>(v + e); ge[i] = *reinterpret_cast<const adam_f4 *>(g + e);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float a = pe[i][c], b = me[i][c], d = ve[i][c];
+        step_form(a, b, d, ge[i][c], false);
+        pe[i][c] = a; me[i][c] = b; ve[i][c] = d;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t e = e0 + (size_t)i * N;
+      *reinterpret_cast<adam_f4 *>(p + e) = pe[i]; *reinterpret_cast<adam_f4 *>(m + e) = me[i];
+      *reinterpret_cast<adam_f4 *>(v + e) = ve[i];
+    }
+    const size_t term = (size_t)K * N;
+    // forward images: half of a 16-byte piece (4 of its 8 consecutive k) per column and term
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x4[4] = {pe[0][c], pe[1][c], pe[2][c], pe[3][c]};
+      split_bf16::bf16x4 q[3];
+      split_bf16::split4(x4, q);
+      uint16_t *dst = wi.img[j] + ((size_t)(g4 >> 1) * N + col + c) * 8 + 4 * (g4 & 1);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) *reinterpret_cast<split_bf16::bf16x4 *>(dst + t * term) = q[t];
+    }
+    // images of the transpose (the backward's): element W[k][n] at ((n >> 3) K + k) 8 + (n & 7) -- 8 bytes per row
+    // and term (4 consecutive n of one k)
+    if (wi.img_r[j]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x4[4] = {pe[i][0], pe[i][1], pe[i][2], pe[i][3]};
+        split_bf16::bf16x4 q[3];
+        split_bf16::split4(x4, q);
+        uint16_t *dst = wi.img_r[j] + ((size_t)(col >> 3) * K + g4 * 4 + i) * 8 + (col & 7);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) *reinterpret_cast<split_bf16::bf16x4 *>(dst + t * term) = q[t];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NORM_BLOCK / 1024; ++i) {
     const size_t o = base + (size_t)(threadIdx.x + 256 * i) * 4;
+    bool in_matrix = false;                    // (begin and size are multiples of 4: a group is inside or outside)
+    for (int j = 0; j < wi.n; ++j) in_matrix |= o >= wi.begin[j] && o < wi.end[j];
+    if (in_matrix) continue;
     if (o + 3 < n) {
       typedef float adam_f4 __attribute__((ext_vector_type(4)));
       adam_f4 pv, mv, vv, gv;
@@ -448,10 +539,10 @@ extern "C" int mtam_adam(float *p, float *m, float *v, const float *g, size_t n,
   dim3 grid(mtam_sqnorm_blocks(n));
   if (n * 4 >= adam_nt_min_bytes())
     hipLaunchKernelGGL((adam_kernel<false, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n,
-                       scale, hyper, sparse_begin, static_cast<uint16_t *>(nullptr), n);
+                       scale, hyper, sparse_begin, static_cast<uint16_t *>(nullptr), n, AdamImages{});
   else
     hipLaunchKernelGGL((adam_kernel<false, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n,
-                       scale, hyper, sparse_begin, static_cast<uint16_t *>(nullptr), n);
+                       scale, hyper, sparse_begin, static_cast<uint16_t *>(nullptr), n, AdamImages{});
   MTAM_CHECK_LAUNCH("adam");
   return MTAM_OK;
 }
@@ -469,11 +560,57 @@ extern "C" int mtam_adam_bf16copy(float *p, float *m, float *v, const float *g, 
   dim3 grid(mtam_sqnorm_blocks(n));
   if (n * 4 >= adam_nt_min_bytes())
     hipLaunchKernelGGL((adam_kernel<true, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n,
-                       scale, hyper, sparse_begin, copy16, copy_begin);
+                       scale, hyper, sparse_begin, copy16, copy_begin, AdamImages{});
   else
     hipLaunchKernelGGL((adam_kernel<true, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p, m, v, g, n,
-                       scale, hyper, sparse_begin, copy16, copy_begin);
+                       scale, hyper, sparse_begin, copy16, copy_begin, AdamImages{});
   MTAM_CHECK_LAUNCH("adam_bf16copy");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_adam_images(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
+                                const float *hyper, size_t sparse_begin, uint16_t *copy16, size_t copy_begin,
+                                const MtamWeightImages *w, int n_w, void *stream) {
+  MTAM_CHECK_ARG(p && m && v && g && scale && hyper && n > 0, "adam_images: bad arguments");
+  MTAM_CHECK_ARG(mtam_aligned16(p) && mtam_aligned16(m) && mtam_aligned16(v) && mtam_aligned16(g) &&
+                     (reinterpret_cast<uintptr_t>(copy16) & 7u) == 0,
+                 "adam_images: buffers must be 16-byte aligned (the bf16 copy 8-byte)");
+  MTAM_CHECK_ARG(sparse_begin >= n || sparse_begin % NORM_BLOCK == 0,
+                 "adam_images: sparse_begin must be a multiple of %d (or >= n)", NORM_BLOCK);
+  MTAM_CHECK_ARG(!copy16 || (copy_begin <= n && copy_begin % 4 == 0), "adam_images: copy_begin must be a multiple of 4");
+  MTAM_CHECK_ARG(n_w >= 0 && n_w <= MTAM_MAX_WEIGHT_IMAGES && (n_w == 0 || w), "adam_images: at most %d matrices",
+                 MTAM_MAX_WEIGHT_IMAGES);
+  AdamImages wi{};
+  wi.n = n_w;
+  wi.n_linear = (unsigned)mtam_sqnorm_blocks(n);
+  const size_t dense_end = sparse_begin < n ? sparse_begin : n;
+  for (int j = 0; j < n_w; ++j) {
+    MTAM_CHECK_ARG(w[j].images && w[j].K > 0 && w[j].K % 8 == 0 && w[j].N > 0 && w[j].N % 4 == 0 && w[j].begin % 4 == 0 &&
+                       w[j].begin + (size_t)w[j].K * w[j].N <= dense_end &&
+                       (reinterpret_cast<uintptr_t>(w[j].images) & 15u) == 0,
+                   "adam_images: matrix %d: K must be a multiple of 8, N and begin multiples of 4, inside the dense "
+                   "(non-sparse) part [0, %zu)", j, dense_end);
+    MTAM_CHECK_ARG((reinterpret_cast<uintptr_t>(w[j].images_r) & 15u) == 0 && (!w[j].images_r || w[j].N % 8 == 0),
+                   "adam_images: matrix %d: images_r must be 16-byte aligned and N a multiple of 8", j);
+    wi.begin[j] = w[j].begin; wi.end[j] = w[j].begin + (size_t)w[j].K * w[j].N;
+    for (int i = 0; i < j; ++i)
+      MTAM_CHECK_ARG(wi.end[i] <= wi.begin[j] || wi.end[j] <= wi.begin[i], "adam_images: matrices %d and %d overlap", i, j);
+    wi.K[j] = w[j].K; wi.N[j] = w[j].N; wi.img[j] = w[j].images; wi.img_r[j] = w[j].images_r;
+    wi.first_block[j + 1] = wi.first_block[j] + (unsigned)(((size_t)(w[j].K / 4) * (w[j].N / 4) + 255) / 256);
+  }
+  dim3 grid(wi.n_linear + wi.first_block[n_w]);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool nt = n * 4 >= adam_nt_min_bytes();
+  const size_t cb = copy16 ? copy_begin : n;
+  if (copy16 && nt)
+    hipLaunchKernelGGL((adam_kernel<true, true>), grid, dim3(256), 0, st, p, m, v, g, n, scale, hyper, sparse_begin, copy16, cb, wi);
+  else if (copy16)
+    hipLaunchKernelGGL((adam_kernel<true, false>), grid, dim3(256), 0, st, p, m, v, g, n, scale, hyper, sparse_begin, copy16, cb, wi);
+  else if (nt)
+    hipLaunchKernelGGL((adam_kernel<false, true>), grid, dim3(256), 0, st, p, m, v, g, n, scale, hyper, sparse_begin, copy16, cb, wi);
+  else
+    hipLaunchKernelGGL((adam_kernel<false, false>), grid, dim3(256), 0, st, p, m, v, g, n, scale, hyper, sparse_begin, copy16, cb, wi);
+  MTAM_CHECK_LAUNCH("adam_images");
   return MTAM_OK;
 }
 

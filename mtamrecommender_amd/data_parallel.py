@@ -180,7 +180,7 @@ class ShardedItemExchange(object):
                             group=self.group)
         else:
             dist.all_gather_into_tensor(item, p.flat_p[self.lo:self.hi], group=self.group)      # in place
-        p.refresh_item16()
+        p.refresh_derived()
 
     def exchange_and_apply(self, bt):
         if self.p.optimizer != "adam":
@@ -192,6 +192,7 @@ class ShardedItemExchange(object):
 def broadcast_parameters(path, src=0, group=None):
     """Replicas start identical (they would anyway with equal seeds; this makes it explicit)."""
     dist.broadcast(path.flat_p, src=src, group=group)
+    path.refresh_derived()
 
 
 def max_over_ranks(value, device):

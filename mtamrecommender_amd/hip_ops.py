@@ -367,13 +367,66 @@ def score16_bwd(E16, P16, lse, target, B, V, scale, d_pred, dE, sq_partial=None)
                                     _p(dE), _p(sq_partial), _stream()), "mtam_score16_bwd")
 
 
-def seq_chain_fwd(ic, W4, pos, R, Wkv, bkv, Wx, bx, zr, x, kv, xproj):
-    """zr, x, kv (optional: Wkv None), xproj from [item | category] rows in one launch."""
+def seq_chain_fwd(ic, W4, pos, R, Wkv, bkv, Wx, bx, zr, x, kv, xproj, w_images=None):
+    """zr, x, kv (optional: Wkv None), xproj from [item | category] rows in one launch.  ``w_images``: the bf16
+    operand images of the three weight matrices (``WeightImageSet.buf``); given, the products run as split-bf16."""
     lib = _lib.load()
     n_kv = Wkv.shape[1] if Wkv is not None else 0
     _lib.check(lib.mtam_seq_chain_fwd(_p(ic), _p(W4), _p(pos), R, _p(Wkv), _p(bkv), n_kv, _p(Wx), _p(bx),
-                                      Wx.shape[1], _p(zr), _p(x), _p(kv) if n_kv else None, _p(xproj), _stream()),
+                                      Wx.shape[1], _p(zr), _p(x), _p(kv) if n_kv else None, _p(xproj),
+                                      _pb(w_images) if w_images is not None else None, _stream()),
                "mtam_seq_chain_fwd")
+
+
+def seq_chain_images_elems(n_kv, n_x):
+    return int(_lib.load().mtam_seq_chain_images_elems(int(n_kv), int(n_x)))
+
+
+def seq_chain_image_offset(which, n_kv):
+    return int(_lib.load().mtam_seq_chain_image_offset(int(which), int(n_kv)))
+
+
+def split_weight_images(W, images):
+    """W [K, N] fp32 (contiguous) -> its three bf16 operand images (one launch)."""
+    K, N = W.shape
+    _lib.check(_lib.load().mtam_split_weight_images(_p(W), K, N, _pb(images), _stream()), "mtam_split_weight_images")
+
+
+def split_weight_rows(W, images_r):
+    """W [K, N] fp32 (contiguous) -> the three bf16 images of its transpose, the operands of products with W^T."""
+    K, N = W.shape
+    _lib.check(_lib.load().mtam_split_weight_rows(_p(W), K, N, _pb(images_r), _stream()), "mtam_split_weight_rows")
+
+
+def seq_chain_bwd_max_k():
+    return _lib.load().mtam_seq_chain_bwd_max_k()
+
+
+def seq_chain_bwd(d_xproj, d_kv, d_xt, zr, R, d_x, d_z, d_ic, w_images_r):
+    """d_x += d_xproj Wx^T + d_kv Wkv^T + d_xt; d_z = d_x where zr > 0; d_ic = d_z W4^T -- one launch."""
+    n_kv = d_kv.shape[1] if d_kv is not None else 0
+    _lib.check(_lib.load().mtam_seq_chain_bwd(_p(d_xproj), d_xproj.shape[1], _p(d_kv), n_kv, _p(d_xt), _p(zr), R,
+                                              _p(d_x), _p(d_z), _p(d_ic), _pb(w_images_r), _stream()),
+               "mtam_seq_chain_bwd")
+
+
+def weight_image_descs(entries):
+    """[(first element in the flat space, K, N, bf16 image tensor[, image tensor of the transpose])] -> the ctypes array
+    mtam_adam_images takes."""
+    arr = (_lib.WeightImages * max(1, len(entries)))()
+    for i, e in enumerate(entries):
+        begin, K, N, img = e[:4]
+        arr[i].begin, arr[i].K, arr[i].N, arr[i].images = int(begin), int(K), int(N), img.data_ptr()
+        arr[i].images_r = e[4].data_ptr() if len(e) > 4 and e[4] is not None else None
+    return arr, len(entries)
+
+
+def adam_images(p, m, v, g, n, scale, hyper, sparse_begin, descs, copy16=None, copy_begin=0):
+    """mtam_adam / mtam_adam_bf16copy that also re-writes the weight matrices' bf16 operand images."""
+    arr, n_w = descs
+    _lib.check(_lib.load().mtam_adam_images(_p(p), _p(m), _p(v), _p(g), n, _p(scale), _p(hyper), int(sparse_begin),
+                                            _pb(copy16) if copy16 is not None else None, int(copy_begin),
+                                            ctypes.cast(arr, ctypes.c_void_p), n_w, _stream()), "mtam_adam_images")
 
 
 def seq_chain_gather_partials(B, L):
@@ -381,7 +434,8 @@ def seq_chain_gather_partials(B, L):
 
 
 def seq_chain_gather_fwd(item_table, cat_table, pos_table, user_table, item_ids, cat_ids, pos_ids, user_ids, B, L,
-                         with_user, W4, Wkv, bkv, Wx, bx, ic_out, user_out, l2_partial, zr, x, kv, xproj, clear=()):
+                         with_user, W4, Wkv, bkv, Wx, bx, ic_out, user_out, l2_partial, zr, x, kv, xproj, clear=(),
+                         w_images=None):
     """The four embedding lookups + dense4emb + K/V projection + GRU input projection in one launch; ic_out None
     in evaluation.  ``clear``: up to two float tensors zeroed on the side."""
     lib = _lib.load()
@@ -393,7 +447,8 @@ def seq_chain_gather_fwd(item_table, cat_table, pos_table, user_table, item_ids,
         _p(user_table), user_table.shape[0], _pi(item_ids), _pi(cat_ids), _pi(pos_ids), _pi(user_ids), B, L,
         int(with_user), _p(W4), _p(Wkv), _p(bkv), n_kv, _p(Wx), _p(bx), Wx.shape[1], _p(ic_out), _p(user_out),
         _p(l2_partial), l2_partial.numel(), _p(zr), _p(x), _p(kv) if n_kv else None, _p(xproj),
-        _p(ca), ca.numel() if ca is not None else 0, _p(cb), cb.numel() if cb is not None else 0, _stream())
+        _p(ca), ca.numel() if ca is not None else 0, _p(cb), cb.numel() if cb is not None else 0,
+        _pb(w_images) if w_images is not None else None, _stream())
     _lib.check(rc, "mtam_seq_chain_gather_fwd")
 
 

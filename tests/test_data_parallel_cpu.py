@@ -123,7 +123,7 @@ class _FakePath(object):
     def gb(self, bt):
         return bt.B * self.world_size
 
-    def refresh_item16(self):
+    def refresh_derived(self):
         self.refreshed += 1
 
 

@@ -973,10 +973,82 @@ def _score32_case(ops, B, V, form):
             1e-7 * float(ref_dE.abs().max())
 
 
+def _weight_images(ops, W4, Wkv, Wx):
+    """The bf16 operand images of the three weight matrices, as mtam_split_weight_images writes them."""
+    n_kv, n_x = (Wkv.shape[1] if Wkv is not None else 0), Wx.shape[1]
+    buf = torch.zeros(ops.seq_chain_images_elems(n_kv, n_x), dtype=torch.bfloat16, device="cuda")
+    for which, W in ((0, W4), (1, Wkv), (2, Wx)):
+        if W is not None:
+            ops.split_weight_images(W, buf[ops.seq_chain_image_offset(which, n_kv):])
+    return buf
+
+
+def test_weight_images_layout_and_exactness(ops):
+    """mtam_split_weight_images: W = W1 + W2 + W3 to the last bit of fp32 (three bf16 terms carry 24 significant
+    bits), stored [K / 8][N][8] per term -- checked element by element against the layout the header states."""
+    rng = np.random.default_rng(5)
+    K, N = 24, 20
+    W = (rng.standard_normal((K, N)) * np.exp(rng.uniform(-8, 8, (K, N)))).astype(np.float32)
+    img = torch.zeros(3 * K * N, dtype=torch.bfloat16, device="cuda")
+    ops.split_weight_images(dev(W), img)
+    terms = img.float().cpu().numpy().reshape(3, K // 8, N, 8).transpose(0, 1, 3, 2).reshape(3, K, N)
+    assert np.array_equal(terms[0], dev(W).bfloat16().float().cpu().numpy())      # term 1 = round-to-nearest bf16
+    total = terms[0].astype(np.float64) + terms[1] + terms[2]
+    assert np.array_equal(total.astype(np.float32), W) and np.abs(total - W).max() <= 2.0 ** -24 * np.abs(W).max()
+
+
+def test_adam_rewrites_the_weight_images(ops):
+    """mtam_adam_images = mtam_adam (same parameters, same slots, bit for bit) + the bf16 operand images of the
+    listed matrices re-written from the UPDATED values -- what mtam_split_weight_images gives afterwards -- with and
+    without the bf16 copy of the tail, matrices at odd places of the flat space, elements outside them untouched."""
+    rng = np.random.default_rng(11)
+    blk = ops.adam_block()
+    n = 3 * blk + 128 * 40 + 8
+    # (begin, K, N): inside the dense part [0, 2 blk), not block-aligned, the last one ending exactly at its end
+    mats = [(256, 16, 128), (256 + 16 * 128 + 4, 128, 36), (2 * blk - 8 * 128, 8, 128)]
+    g, p0 = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    m0, v0 = (rng.standard_normal(n) * 0.1).astype(np.float32), rng.uniform(0, 0.1, n).astype(np.float32)
+    scale = dev(np.array([0.7, 1.0], np.float32))
+    hyper = dev(np.array([1e-3, 0.9, 0.999, 1e-8], np.float32))
+    for copy in (False, True):
+        p, m, v = dev(p0), dev(m0), dev(v0)
+        ops.adam(p, m, v, dev(g), n, scale, hyper, 2 * blk)
+        p2, m2, v2 = dev(p0), dev(m0), dev(v0)
+        imgs = [torch.full((3 * K * N,), 7.0, dtype=torch.bfloat16, device="cuda") for _, K, N in mats]
+        imgs_r = [torch.full((3 * K * N,), 7.0, dtype=torch.bfloat16, device="cuda") if N % 8 == 0 else None
+                  for _, K, N in mats]
+        descs = ops.weight_image_descs([(b, K, N, im, ir) for (b, K, N), im, ir in zip(mats, imgs, imgs_r)])
+        copy16 = torch.zeros(n - 2 * blk, dtype=torch.bfloat16, device="cuda") if copy else None
+        ops.adam_images(p2, m2, v2, dev(g), n, scale, hyper, 2 * blk, descs, copy16=copy16, copy_begin=2 * blk)
+        assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2)
+        for (b, K, N), im in zip(mats, imgs):
+            want = torch.zeros_like(im)
+            ops.split_weight_images(p2[b:b + K * N].view(K, N), want)
+            assert torch.equal(im, want)
+        for (b, K, N), ir in zip(mats, imgs_r):
+            if ir is not None:                      # the images of the transpose (the backward's operands)
+                want = torch.zeros_like(ir)
+                ops.split_weight_rows(p2[b:b + K * N].view(K, N), want)
+                assert torch.equal(ir, want)
+                # the layout the header states: the wimg layout of W^T -- [N / 8][K][8] per term
+                terms = ir.float().view(3, N // 8, K, 8).permute(0, 2, 1, 3).reshape(3, K, N)
+                assert torch.equal((terms[0].double() + terms[1].double() + terms[2].double()).float(),
+                                   p2[b:b + K * N].view(K, N))
+        if copy:
+            assert torch.equal(copy16, p2[2 * blk:].bfloat16())
+    with pytest.raises(RuntimeError):           # K must be a multiple of 8
+        ops.adam_images(p2, m2, v2, dev(g), n, scale, hyper, 2 * blk, ops.weight_image_descs([(0, 12, 128, imgs[0])]))
+    with pytest.raises(RuntimeError):           # a matrix among the table rows (IndexedSlices update form) is refused
+        ops.adam_images(p2, m2, v2, dev(g), n, scale, hyper, blk, ops.weight_image_descs([mats[2] + (imgs[2],)]))
+
+
+@pytest.mark.parametrize("x3", [False, True])
 @pytest.mark.parametrize("R,n_kv,n_x", [(6400, 256, 384), (100, 512, 384), (33, 0, 384), (777, 256, 640)])
-def test_seq_chain_fwd_matches_the_three_products(ops, R, n_kv, n_x):
+def test_seq_chain_fwd_matches_the_three_products(ops, R, n_kv, n_x, x3):
     """mtam_seq_chain_fwd = dense4emb (relu, + position), K/V projection (bias, relu) and the GRU input
-    projection (bias) of the forward step; float64 reference, fp32 MFMA sums: 2e-5 of the largest entry."""
+    projection (bias) of the forward step; float64 reference, fp32 MFMA sums: 2e-5 of the largest entry.
+    x3: the same products as six bf16-MFMA terms of split operands (weights pre-split into images) -- the SAME
+    tolerance, and no further from float64 than 2 x a native fp32 matmul of the operands is."""
     rng = np.random.default_rng(R + n_kv + n_x)
     ic = rng.standard_normal((R, 2 * D)).astype(np.float32)
     pos = rng.standard_normal((R, D)).astype(np.float32)
@@ -989,9 +1061,15 @@ def test_seq_chain_fwd_matches_the_three_products(ops, R, n_kv, n_x):
     x = torch.full((R, D), 9.0, device="cuda")
     kv = torch.full((R, max(n_kv, 1)), 9.0, device="cuda")
     xproj = torch.full((R, n_x), 9.0, device="cuda")
-    ops.seq_chain_fwd(dev(ic), dev(W4), dev(pos), R, dev(np.ascontiguousarray(Wkv)) if n_kv else None,
-                      dev(bkv) if n_kv else None, dev(Wx), dev(bx), zr, x, kv if n_kv else None, xproj)
+    Wkv_d = dev(np.ascontiguousarray(Wkv)) if n_kv else None
+    images = _weight_images(ops, dev(W4), Wkv_d, dev(Wx)) if x3 else None
+    ops.seq_chain_fwd(dev(ic), dev(W4), dev(pos), R, Wkv_d, dev(bkv) if n_kv else None, dev(Wx), dev(bx), zr, x,
+                      kv if n_kv else None, xproj, w_images=images)
     z64 = ic.astype(np.float64) @ W4.astype(np.float64)
+    if x3:
+        nat = (dev(ic) @ dev(W4)).double().cpu().numpy()
+        got_z = np.where(zr.cpu().numpy() > 0, zr.cpu().numpy().astype(np.float64), z64)     # (relu'd entries: skip)
+        assert np.abs(got_z - z64).max() <= 2.0 * np.abs(nat - z64).max() + 1e-7 * np.abs(z64).max()
     zr64 = np.maximum(z64, 0.0)
     x64 = zr64 + pos
     assert rel_err(zr.cpu().numpy(), zr64) < 2e-5 and rel_err(x.cpu().numpy(), x64) < 2e-5
@@ -1001,6 +1079,54 @@ def test_seq_chain_fwd_matches_the_three_products(ops, R, n_kv, n_x):
     # the relu mask the backward uses is exact where the pre-activation is not within rounding of zero
     clear = np.abs(z64) > 1e-4
     assert np.array_equal((zr.cpu().numpy() > 0)[clear], (z64 > 0)[clear])
+
+
+@pytest.mark.parametrize("R,n_kv", [(6400, 256), (100, 128), (33, 0), (777, 256), (1, 256)])
+def test_seq_chain_bwd_matches_the_two_gemms(ops, R, n_kv):
+    """mtam_seq_chain_bwd (the backward's sequence-side chain as one stripe kernel): d_x += d_xproj Wx^T + d_kv Wkv^T
+    + d_xt, d_z = d_x where zr > 0, d_ic = d_z W4^T -- against float64 (2e-5 of the largest entry, the tolerance of
+    the GEMMs it replaces; no further from float64 than 2 x a native fp32 matmul) and against the two-launch form
+    (mtam_gemm_f32_dual ACCUM2_MASK + mtam_gemm_f32): the same mask, values to fp32 rounding."""
+    rng = np.random.default_rng(R + n_kv)
+    n_x = 384
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    d_xproj, d_kv, d_xt, d_x0 = f(R, n_x), f(R, max(n_kv, 1))[:, :n_kv], f(R, D), f(R, D)
+    zr = np.maximum(f(R, D), 0.0)
+    Wx, Wkv, W4 = f(D, n_x) * 0.1, np.ascontiguousarray((f(D, max(n_kv, 8)) * 0.1)[:, :n_kv]), f(2 * D, D) * 0.1
+    n_img = ops.seq_chain_images_elems(n_kv, n_x)
+    img_r = torch.zeros(n_img, dtype=torch.bfloat16, device="cuda")
+    for which, W in ((0, W4), (1, Wkv), (2, Wx)):
+        if W.size:
+            ops.split_weight_rows(dev(W), img_r[ops.seq_chain_image_offset(which, n_kv):])
+    d_x, d_z, d_ic = dev(d_x0), torch.full((R, D), 9.0, device="cuda"), torch.full((R, 2 * D), 9.0, device="cuda")
+    d_kv_d = dev(np.ascontiguousarray(d_kv)) if n_kv else None
+    ops.seq_chain_bwd(dev(d_xproj), d_kv_d, dev(d_xt), dev(zr), R, d_x, d_z, d_ic, img_r)
+    f64 = lambda a: a.astype(np.float64)
+    dx64 = f64(d_x0) + f64(d_xproj) @ f64(Wx).T + (f64(d_kv) @ f64(Wkv).T if n_kv else 0.0) + f64(d_xt)
+    dz64 = np.where(zr > 0, dx64, 0.0)
+    dic64 = dz64 @ f64(W4).T
+    assert rel_err(d_x.cpu().numpy(), dx64) < 2e-5 and rel_err(d_ic.cpu().numpy(), dic64) < 2e-5
+    got_z = d_z.cpu().numpy()
+    assert np.array_equal(got_z != 0, (zr > 0) & (d_x.cpu().numpy() != 0)) and rel_err(got_z, dz64) < 2e-5
+    assert np.array_equal(got_z[zr > 0], d_x.cpu().numpy()[zr > 0])          # d_z is d_x itself under the mask
+    nat = (dev(d_x0) + dev(d_xproj) @ dev(Wx).T + (d_kv_d @ dev(Wkv).T if n_kv else 0.0) + dev(d_xt)).double().cpu().numpy()
+    assert np.abs(d_x.cpu().numpy() - dx64).max() <= 2.0 * np.abs(nat - dx64).max() + 1e-7 * np.abs(dx64).max()
+    # the two-launch form it replaces
+    d_x2, d_z2, d_ic2 = dev(d_x0), torch.zeros((R, D), device="cuda"), torch.zeros((R, 2 * D), device="cuda")
+    if n_kv:
+        ops.gemm_dual(dev(d_xproj), dev(Wx), d_kv_d, dev(Wkv), d_x2, trans_b=True, epilogue=ops.EPI_ACCUM2_MASK,
+                      bias=dev(d_xt), aux_in=dev(zr), aux_out=d_z2)
+    else:
+        ops.gemm(dev(d_xproj), dev(Wx), d_x2, trans_b=True, epilogue=ops.EPI_ACCUM2_MASK, bias=dev(d_xt),
+                 aux_in=dev(zr), aux_out=d_z2)
+    ops.gemm(d_z2, dev(W4), d_ic2, trans_b=True)
+    assert rel_err(d_x.cpu().numpy(), d_x2.cpu().numpy()) < 1e-5 and rel_err(d_ic.cpu().numpy(), d_ic2.cpu().numpy()) < 1e-5
+    assert torch.equal(d_z != 0, d_z2 != 0)
+    with pytest.raises(RuntimeError):           # widths are multiples of 128 ...
+        ops.seq_chain_bwd(dev(d_xproj)[:, :320].contiguous(), d_kv_d, dev(d_xt), dev(zr), R, d_x, d_z, d_ic, img_r)
+    with pytest.raises(RuntimeError):           # ... and the staged stripe holds n_x + n_kv <= 640 (one decoder block)
+        ops.seq_chain_bwd(dev(d_xproj), torch.zeros((R, 512), device="cuda"), dev(d_xt), dev(zr), R, d_x, d_z, d_ic, img_r)
+    assert ops.seq_chain_bwd_max_k() == 640
 
 
 @pytest.mark.parametrize("rows,V,slab", [(5, 300000, 131072), (3, 65536 * 3, 65536), (2, 70000, 65536 * 2)])
@@ -1040,8 +1166,9 @@ def test_topk_stream_equals_topk_on_the_stored_matrix(ops, rows, V, slab):
         ops.topk_stream_slab(scratch, slab, rows, 1000, 10, V, k, ws)
 
 
+@pytest.mark.parametrize("x3", [False, True])
 @pytest.mark.parametrize("B,L,with_user,train", [(128, 50, 1, True), (7, 9, 0, True), (33, 50, 1, False), (1, 2, 1, True)])
-def test_seq_chain_gather_fwd_equals_gather_then_chain(ops, B, L, with_user, train):
+def test_seq_chain_gather_fwd_equals_gather_then_chain(ops, B, L, with_user, train, x3):
     """mtam_seq_chain_gather_fwd (the four lookups folded into the forward's first GEMM kernel) against
     mtam_emb_gather_fwd + mtam_seq_chain_fwd: bit-identical zr / x / kv / xproj / user rows and (training) the
     [item | category] copy; the l2 sum to rounding; side ranges cleared; out-of-range ids clamped the same way."""
@@ -1064,7 +1191,8 @@ def test_seq_chain_gather_fwd_equals_gather_then_chain(ops, B, L, with_user, tra
     ops.emb_gather_fwd(T["item"], T["cat"], T["pos"], T["user"], ids["item"], ids["cat"], ids["pos"], ids["user"], B, L,
                        with_user, ic, pos, user, l2a)
     ref = [z(R, D), z(R, D), z(R, n_kv), z(R, n_x)]
-    ops.seq_chain_fwd(ic, W4, pos, R, Wkv, bkv, Wx, bx, *ref)
+    images = _weight_images(ops, W4, Wkv, Wx) if x3 else None         # (both forms: split-bf16 products too)
+    ops.seq_chain_fwd(ic, W4, pos, R, Wkv, bkv, Wx, bx, *ref, w_images=images)
     # fused
     got = [z(R, D), z(R, D), z(R, n_kv), z(R, n_x)]
     ic2, user2 = z(R, 2 * D), z(B, D)
@@ -1072,7 +1200,7 @@ def test_seq_chain_gather_fwd_equals_gather_then_chain(ops, B, L, with_user, tra
     ca, cb = torch.ones(4 * 1000, device="cuda"), torch.ones(4 * 77, device="cuda")
     ops.seq_chain_gather_fwd(T["item"], T["cat"], T["pos"], T["user"], ids["item"], ids["cat"], ids["pos"], ids["user"],
                              B, L, with_user, W4, Wkv, bkv, Wx, bx, ic2 if train else None, user2, l2b, *got,
-                             clear=(ca, cb))
+                             clear=(ca, cb), w_images=images)
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
     assert torch.equal(user2, user)

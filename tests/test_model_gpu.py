@@ -447,6 +447,42 @@ def test_dead_variables_get_no_gradient_and_no_update(hip_lib, tmp_path, model_n
             assert not np.array_equal(before[k], after[k]), k
 
 
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_weight_images_follow_the_weights(hip_lib, tmp_path, optimizer):
+    """The bf16 operand images the forward's fused projection kernel reads (dense4emb/w, kv/w, gru/wx) are derived
+    state: after optimizer steps (Adam re-writes them in its own launch; the other optimizers refresh them behind
+    theirs), after set_variables() and after restore() they equal a fresh split of the current fp32 weights, bit
+    for bit -- a stale image would train on last step's weights."""
+    from mtamrecommender_amd import hip_ops as ops
+    model, FLAGS, records = build(tmp_path, 16, 8, 2, 1, optimizer=optimizer)
+    p = model.path
+    assert p.wimg is not None and [n for n, *_ in p._wimg_parts] == ["dense4emb/w", "kv/w", "gru/wx"]
+
+    def fresh():
+        n_img = p.wimg.numel()
+        buf = torch.zeros(2 * n_img, dtype=torch.bfloat16, device="cuda")
+        n_kv = p.layout.segments["kv/w"].shape[1]
+        for which, name in enumerate(("dense4emb/w", "kv/w", "gru/wx")):
+            o = ops.seq_chain_image_offset(which, n_kv)
+            ops.split_weight_images(p.seg(name), buf[o:])
+            ops.split_weight_rows(p.seg(name), buf[n_img + o:])
+        return buf
+
+    whole = lambda: torch.cat([p.wimg, p.wimg_r])
+    assert torch.equal(whole(), fresh())
+    w0 = p.seg("gru/wx").clone()
+    for _ in range(3):
+        model.train(model.sess, records, 1e-3)
+    assert not torch.equal(p.seg("gru/wx"), w0) and torch.equal(whole(), fresh())
+    model.save(model.sess, global_step=1)
+    arrays = model.get_variables()
+    arrays["position_embedding/dense4emb/kernel"] = arrays["position_embedding/dense4emb/kernel"] * 1.5
+    model.set_variables(arrays)
+    assert torch.equal(whole(), fresh())
+    model.restore(model.sess, str(tmp_path))
+    assert torch.equal(whole(), fresh())
+
+
 def test_async_loss_is_logged_once_under_its_own_step(hip_lib, tmp_path):
     """async_loss: train() hands over the PREVIOUS step's loss together with the step it belongs to, nothing on the
     first call, and drain_loss() the most recent one -- so a loop sees every step's loss exactly once, equal to
