@@ -380,6 +380,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--score-dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: logits-free bf16-MFMA catalog scoring (BASELINE.json configs[4]); default fp32")
+    ap.add_argument("--dp-exchange", default=None, choices=["flat", "sharded", "sharded-scoring"],
+                    help="data-parallel gradient exchange (default: by catalog size -- flat below 64 MiB of item "
+                         "table, sharded above; sharded-scoring: the item table row-sharded for scoring too)")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="stub ranks over gloo, no GPU: checks launcher, rendezvous and the one-line protocol")
     ap.add_argument("--no-scale-legs", action="store_true", help="skip roofline_at_scale (B = 512 / 2,048 legs)")
@@ -448,7 +451,7 @@ def main():
     model = (MTAM if args.model == "MTAM" else Time_Aware_self_Attention_model)(FLAGS, emb, Session(device))
     p = model.path
     if use_dist:
-        data_parallel.attach(p, world, force=force_dp)
+        data_parallel.attach(p, world, force=force_dp, exchange=args.dp_exchange)
         data_parallel.broadcast_parameters(p)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     arrays0 = model.get_variables() if want_cpu else None
@@ -597,8 +600,12 @@ def main():
                       "fp32 matmul's error); fused forward projections: native fp32 MFMA; GRU / attention / "
                       "optimizer / lookups: fp32 VALU; evaluation scores: k-ordered fp32 fmaf chain"),
             "data": "synthetic", "ranks_seen": ranks_seen, "ms_per_step_by_rank": per_rank_ms,
-            "exchange": (None if not use_dist else "row-sharded item exchange (reduce-scatter + owned Adam + "
-                         "all-gather)" if p.sharded is not None else "flat all-reduce of every gradient"),
+            "exchange": (None if not use_dist else
+                         {"flat": "flat all-reduce of every gradient",
+                          "sharded": "row-sharded item exchange (reduce-scatter + owned Adam + all-gather)",
+                          "sharded-scoring": "item table row-sharded for scoring too (all-gather pred, reduced lse and "
+                                             "d_pred, dE born sharded, slot exchange, owned Adam, all-gather)"}
+                         [p.dp_exchange]),
             "config": {"workload": "%s training step, %s synthetic (%d items, %d categories, %d users), seq_len=%d "
                                    "emb=128 num_blocks=%d num_heads=%d, batch=%d per GPU"
                                    % ("MTAMRec" if args.model == "MTAM" else "PISTRec (Time_Aware_self_Attention_model)",

@@ -222,6 +222,17 @@ int mtam_emb_scatter_add_bwd_fused(const float *d_item_cat, const float *d_z, co
                                    int L, float reg, int with_user, float *g_item, int item_rows, float *g_cat,
                                    int cat_rows, float *g_pos, int pos_rows, float *g_user, int user_rows,
                                    float *slot_sq_partial, void *stream);
+/* ... restricted to a ROW RANGE of the item table (data-parallel row-sharded scoring: a rank owns item rows
+ * [item_lo, item_hi) of the gradient): item slots whose id lies outside the range are skipped; every other table as
+ * in mtam_emb_scatter_add_bwd_fused.  item_only != 0: ONLY the item slots are applied (another rank's all-gathered
+ * d_item_cat / item_cat / item_ids / seq_len: the item halves of its [B*L, 2D] rows); every other pointer may be NULL. */
+int mtam_emb_scatter_add_bwd_range(const float *d_item_cat, const float *d_z, const float *W4, const float *d_pos,
+                                   const float *item_cat, const float *pos, const float *pos_table,
+                                   const float *user, const int32_t *item_ids, const int32_t *cat_ids,
+                                   const int32_t *pos_ids, const int32_t *user_ids, const int32_t *seq_len, int B,
+                                   int L, float reg, int with_user, float *g_item, int item_rows, float *g_cat,
+                                   int cat_rows, float *g_pos, int pos_rows, float *g_user, int user_rows,
+                                   float *slot_sq_partial, int item_lo, int item_hi, int item_only, void *stream);
 
 /* ----------------------------------------------------------- time-aware GRU
  * dynamic_rnn(TimeAwareGRUCell_decay_new) + gather_indexes(seq_len - 2):
@@ -437,6 +448,19 @@ int mtam_score32_lse(const float *E, const float *pred, const int32_t *target, i
                      int n_partial, float *lse, float *ce, void *stream);
 int mtam_score32_bwd(const float *E, const float *pred, const float *lse, const int32_t *target, int B, int V,
                      float scale, float *d_pred, float *dE, float *sq_partial, int n_sq_partial, void *stream);
+/* The same two passes over a ROW RANGE of the catalog (data-parallel row-sharded scoring, SURVEY.md 8(e): every rank
+ * scores its own V / G rows against the all-gathered pred of the whole batch; Model/base_model.py:309-322): E points
+ * at the range's first row, V = rows in the range, row0 = that row's catalog number, `target` holds CATALOG row
+ * numbers.  mtam_score32_lse_range: lse[b] = log-sum-exp over the range's rows only and ce[b] = the TARGET LOGIT if
+ * the target lies in the range, else 0 (the caller combines the ranks' pairs: lse = log sum_r exp(lse_r), logit =
+ * sum_r logit_r).  mtam_score32_bwd_range: `lse` is the combined one; a target outside the range gets no one-hot
+ * term; dE [V, 128] covers the range's rows and is COMPLETE (summed over the whole batch); d_pred is the range's
+ * share and is summed over ranks by the caller. */
+int mtam_score32_lse_range(const float *E, const float *pred, const int32_t *target, int B, int V, int row0,
+                           float *partial, int n_partial, float *lse, float *ce, void *stream);
+int mtam_score32_bwd_range(const float *E, const float *pred, const float *lse, const int32_t *target, int B, int V,
+                           int row0, float scale, float *d_pred, float *dE, float *sq_partial, int n_sq_partial,
+                           void *stream);
 
 /* ------------------------------------------- the forward's three sequence-side projections in one launch
  *   zr = relu(ic W4) ; x = zr + pos                       (Embedding/...attention.py:95-103; = mtam_gemm_f32 RELU_ADD)

@@ -273,6 +273,14 @@ class base_model(object):
         the fused form has only been run with a one-rank group (this build's GPU box has one GPU), and a
         collective that misbehaves inside a replayed graph cannot be recovered from -- ``fused`` otherwise."""
         p = self.path
+        if getattr(p, "sharded_scoring", None) is not None:
+            # scoring row-sharded over the ranks: forward to pred (graph), the two scoring passes with their small
+            # collectives (eager), backward from d_pred (graph), exchange + update (eager)
+            self._run("train_pre", bt, p.forward_to_pred_kernels)
+            p.sharded_scoring.score(bt)
+            self._run("train_post", bt, p.backward_from_pred_kernels)
+            p.sharded_scoring.exchange_and_apply(bt)
+            return
         if getattr(p, "sharded", None) is not None:
             # large catalogs: forward + backward as one graph, then the row-sharded exchange and update eagerly
             # (a handful of launches between collectives; the step is milliseconds long at these sizes)

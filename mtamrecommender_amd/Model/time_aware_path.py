@@ -284,6 +284,8 @@ class TimeAwarePath(object):
         self.loss_in_tail = False       # data_parallel.attach(): the reported loss is the all-reduced tail
         self.allreduce_fn = None        # set by data_parallel.attach()
         self.sharded = None             # data_parallel.ShardedItemExchange: replaces allreduce_fn + clip_and_apply
+        self.sharded_scoring = None     # data_parallel.ShardedScoringExchange: scoring itself is row-sharded
+        self.dp_exchange = None
         self.world_size = 1             # the loss is a mean over world_size * B samples ...
         self.global_batch = None        # ... or over exactly this many when the ranks' batches differ in size
 
@@ -507,7 +509,9 @@ class TimeAwarePath(object):
                             bt.ce_partial, bt.l2_live, bt.l2_live.numel(), self.reg, 1.0 / gb, None)
 
     # ---------------------------------------------------------------- backward
-    def backward(self, bt):
+    def backward(self, bt, score=True):
+        """score=False: d_pred is already there (data-parallel row-sharded scoring formed it and the rank's own rows
+        of the item gradient); the scatter-add then touches this rank's item rows only."""
         B, R, L, NB, H = bt.B, bt.R, self.L, self.NB, self.H
         fd, T, G, cfg = bt.feed, self.tables, self.grads, self.cfg
         gseg = lambda name: self.layout.view(G, name)
@@ -517,7 +521,8 @@ class TimeAwarePath(object):
         sr = max(1, min(int(os.environ.get("MTAM_WGRAD_SPLIT", "12")), R // 256))
         prob = lambda A, lda, Bm, ldb, name, M, N, K, s: dict(A=A, lda=lda, B=Bm, ldb=ldb, C=gseg(name),
                                                               ldc=N, M=M, N=N, K=K, split_k=s)
-        self.score_backward(bt)          # d_pred -> head LN -> decoder blocks (last to first)
+        if score:
+            self.score_backward(bt)      # d_pred -> head LN -> decoder blocks (last to first)
         if bt.concat_head:               # back through output_w: d(ln_out) now, d(short) after the decoder
             W = self.seg("head/output_w")
             ops.gemm(bt.d_pred, W[D:], bt.d_ln_out, trans_b=True)
@@ -630,7 +635,9 @@ class TimeAwarePath(object):
                                 self.g_tab["position"], self.g_tab["user"], slot_part,
                                 pos_table=T["position"] if fused else None,
                                 d_z=bt.d_z if fused_scatter else None,
-                                W4=self.seg("dense4emb/w") if fused_scatter else None)
+                                W4=self.seg("dense4emb/w") if fused_scatter else None,
+                                item_range=(self.sharded_scoring.row_lo, self.sharded_scoring.row_hi)
+                                if self.sharded_scoring is not None else None)
 
     # ------------------------------------------------------------------ update
     def clip_and_apply(self, bt):
@@ -669,8 +676,22 @@ class TimeAwarePath(object):
         self.loss_and_logit_grad(bt)
         self.backward(bt)
 
+    # the two halves of a step under data-parallel row-sharded scoring (the scoring passes and their collectives run
+    # between them: data_parallel.ShardedScoringExchange.score)
+    def forward_to_pred_kernels(self, bt):
+        self.forward(bt, training=True, score=False)
+
+    def backward_from_pred_kernels(self, bt):
+        self.backward(bt, score=False)
+
     def train_kernels(self, bt):
         """Everything between feed upload and loss read-back; capturable."""
+        if self.sharded_scoring is not None:
+            self.forward_to_pred_kernels(bt)
+            self.sharded_scoring.score(bt)
+            self.backward_from_pred_kernels(bt)
+            self.sharded_scoring.exchange_and_apply(bt)
+            return
         self.forward_backward_kernels(bt)
         if self.sharded is not None:
             self.sharded.exchange_and_apply(bt)

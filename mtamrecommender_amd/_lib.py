@@ -41,6 +41,8 @@ SIGNATURES = {
                                                 P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
     "mtam_emb_scatter_add_bwd_fused": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
                                                P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
+    "mtam_emb_scatter_add_bwd_range": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
+                                               P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P]),
     "mtam_seq_chain_gather_partials": (c_int, [c_int, c_int]),
     "mtam_seq_chain_gather_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
                                           P, P, P, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P, P, c_size_t, P,
@@ -94,6 +96,8 @@ SIGNATURES = {
     "mtam_score32_partials": (c_int, [c_int, c_int]),
     "mtam_score32_sq_partials": (c_int, [c_int]),
     "mtam_score32_lse": (c_int, [P, P, P, c_int, c_int, P, c_int, P, P, P]),
+    "mtam_score32_lse_range": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int, P, P, P]),
+    "mtam_score32_bwd_range": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, c_int, P]),
     "mtam_score32_bwd": (c_int, [P, P, P, P, c_int, c_int, c_float, P, P, P, c_int, P]),
     "mtam_score16_logits": (c_int, [P, P, c_int, c_int, P, ctypes.c_long, P]),
     "mtam_sqnorm_blocks": (c_int, [c_size_t]),

@@ -143,6 +143,10 @@ struct ScatterArgs {
   // item (category) table computes its own 128 x 128 block  d_z[chunk rows] . W4[table half]^T  on the matrix cores
   // (dense4emb's input gradient, Embedding/Behavior_embedding_time_aware_attention.py:95-101 under tf.gradients)
   const float *d_z, *W4;
+  // data-parallel row-sharded scoring (mtam_emb_scatter_add_bwd_range): only item slots whose id lies in
+  // [item_lo, item_hi) are added (the rank's own rows of the item gradient); n_cat = 0 drops the category chunks
+  // (n_tr = n_user = 0 the others) when another rank's slots are applied to the item rows alone
+  int item_lo, item_hi, n_cat;
 };
 
 // Scatter-add with a per-workgroup duplicate pre-reduction.
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
   const int hw = tid >> 5;
   const int wave_in_block = tid >> 6;
   const int R = p.B * p.L;
-  const int n_work = 2 * p.n_rm + p.n_tr + p.n_user;
+  const int n_work = p.n_rm + p.n_cat + p.n_tr + p.n_user;
 
   if ((int)blockIdx.x == n_work) {
     // Padded slots: every one of them holds row 0 of its table and a zero upstream
@@ -202,16 +206,19 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
     if (n_pad > 0) {
       const float w = p.reg * (float)n_pad;
       const int r = first;
-      float *gi = p.g_item + (size_t)clamp_id(p.item_ids[r], p.item_rows) * D;
-      float *gc = p.g_cat + (size_t)clamp_id(p.cat_ids[r], p.cat_rows) * D;
-      float *gp = p.g_pos + (size_t)clamp_id(p.pos_ids[r], p.pos_rows) * D;
+      const int iid = clamp_id(p.item_ids[r], p.item_rows);
+      const bool do_item = iid >= p.item_lo && iid < p.item_hi, do_cat = p.n_cat > 0, do_pos = p.n_tr > 0;
+      float *gi = p.g_item + (size_t)iid * D;
+      float *gc = do_cat ? p.g_cat + (size_t)clamp_id(p.cat_ids[r], p.cat_rows) * D : nullptr;
+      float *gp = do_pos ? p.g_pos + (size_t)clamp_id(p.pos_ids[r], p.pos_rows) * D : nullptr;
       for (int e = lane; e < D; e += 64) {
-        const float vi = p.ic[(size_t)r * 2 * D + e], vc = p.ic[(size_t)r * 2 * D + D + e];
-        const float vp = p.pos_table ? p.pos_table[(size_t)clamp_id(p.pos_ids[r], p.pos_rows) * D + e]
-                                     : p.pos[(size_t)r * D + e];
-        atomicAdd(gi + e, w * vi);
-        atomicAdd(gc + e, w * vc);
-        atomicAdd(gp + e, w * vp);
+        const float vi = do_item ? p.ic[(size_t)r * 2 * D + e] : 0.f, vc = do_cat ? p.ic[(size_t)r * 2 * D + D + e] : 0.f;
+        const float vp = !do_pos ? 0.f
+                         : p.pos_table ? p.pos_table[(size_t)clamp_id(p.pos_ids[r], p.pos_rows) * D + e]
+                                       : p.pos[(size_t)r * D + e];
+        if (do_item) atomicAdd(gi + e, w * vi);
+        if (do_cat) atomicAdd(gc + e, w * vc);
+        if (do_pos) atomicAdd(gp + e, w * vp);
         const float a = p.reg * vi, b = p.reg * vc, c = p.reg * vp;
         sq += (float)n_pad * (a * a + b * b + c * c);
       }
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
   // ---- which table and which chunk (block-uniform)
   int c = blockIdx.x, table;
   if (c < p.n_rm) table = 0;
-  else if ((c -= p.n_rm) < p.n_rm) table = 1;
+  else if ((c -= p.n_rm) < p.n_cat) table = 1;
   else if ((c -= p.n_rm) < p.n_tr) table = 2;
   else { c -= p.n_tr; table = 3; }
   const float *d_base, *e_base;
@@ -331,8 +338,9 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
   int n_in[SPH];                                  // own slots summed into slot k (0: dead or merged away)
 #pragma unroll
   for (int k = 0; k < SPH; ++k) {
-    const bool live = cand[k] >= 0 && tt[k] < min(max(sl[k], 0), p.L);
     id[k] = clamp_id(id[k], rows);
+    const bool live = cand[k] >= 0 && tt[k] < min(max(sl[k], 0), p.L) &&
+                      (table != 0 || (id[k] >= p.item_lo && id[k] < p.item_hi));
     n_in[k] = live ? 1 : 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -513,8 +521,37 @@ extern "C" int mtam_emb_scatter_add_bwd_fused(const float *d_item_cat, const flo
                                               int with_user, float *g_item, int item_rows, float *g_cat, int cat_rows,
                                               float *g_pos, int pos_rows, float *g_user, int user_rows,
                                               float *slot_sq_partial, void *stream) {
+  return mtam_emb_scatter_add_bwd_range(d_item_cat, d_z, W4, d_pos, item_cat, pos, pos_table, user, item_ids, cat_ids,
+                                        pos_ids, user_ids, seq_len, B, L, reg, with_user, g_item, item_rows, g_cat,
+                                        cat_rows, g_pos, pos_rows, g_user, user_rows, slot_sq_partial, 0, item_rows, 0,
+                                        stream);
+}
+
+extern "C" int mtam_emb_scatter_add_bwd_range(const float *d_item_cat, const float *d_z, const float *W4,
+                                              const float *d_pos, const float *item_cat, const float *pos,
+                                              const float *pos_table, const float *user, const int32_t *item_ids,
+                                              const int32_t *cat_ids, const int32_t *pos_ids,
+                                              const int32_t *user_ids, const int32_t *seq_len, int B, int L, float reg,
+                                              int with_user, float *g_item, int item_rows, float *g_cat, int cat_rows,
+                                              float *g_pos, int pos_rows, float *g_user, int user_rows,
+                                              float *slot_sq_partial, int item_lo, int item_hi, int item_only,
+                                              void *stream) {
   MTAM_CHECK_ARG(B > 0 && L > 0, "emb_scatter: B and L must be positive");
   MTAM_CHECK_ARG((long)B * L * 3 + B < 0x3fffffffL, "emb_scatter: batch too large");
+  MTAM_CHECK_ARG(0 <= item_lo && item_lo <= item_hi && item_hi <= item_rows, "emb_scatter: bad item row range [%d, %d)",
+                 item_lo, item_hi);
+  if (item_only) {
+    // another rank's slots applied to this rank's item rows: only the item halves and the item ids are read
+    MTAM_CHECK_ARG(d_item_cat && item_cat && item_ids && seq_len && g_item && slot_sq_partial && item_rows > 0,
+                   "emb_scatter (item only): null argument");
+    ScatterArgs a{d_item_cat, nullptr, item_cat, nullptr, nullptr, item_ids, nullptr, nullptr, nullptr, seq_len,
+                  B, L, 0, reg, g_item, nullptr, nullptr, nullptr, item_rows, 1, 1, 1, slot_sq_partial,
+                  scatter_rm_chunks(B, L), 0, 0, mtam_emb_scatter_partials(B, L), nullptr, nullptr, nullptr,
+                  item_lo, item_hi, 0};
+    hipLaunchKernelGGL(emb_scatter_kernel, dim3(a.n_rm + 1), dim3(SCATTER_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    MTAM_CHECK_LAUNCH("emb_scatter");
+    return MTAM_OK;
+  }
   MTAM_CHECK_ARG((d_item_cat || (d_z && W4)) && d_pos && item_cat && (pos || pos_table) && user,
                  "emb_scatter: null gradient or gathered rows");
   MTAM_CHECK_ARG(d_item_cat || (mtam_aligned16(d_z) && mtam_aligned16(W4)),
@@ -527,8 +564,8 @@ extern "C" int mtam_emb_scatter_add_bwd_fused(const float *d_item_cat, const flo
                 item_rows, cat_rows, pos_rows, user_rows, slot_sq_partial,
                 scatter_rm_chunks(B, L), scatter_tr_chunks(B, L), with_user ? scatter_user_chunks(B) : 0,
                 mtam_emb_scatter_partials(B, L), pos ? nullptr : pos_table, d_item_cat ? nullptr : d_z,
-                d_item_cat ? nullptr : W4};
-  hipLaunchKernelGGL(emb_scatter_kernel, dim3(2 * a.n_rm + a.n_tr + a.n_user + 1), dim3(SCATTER_THREADS), 0,
+                d_item_cat ? nullptr : W4, item_lo, item_hi, scatter_rm_chunks(B, L)};
+  hipLaunchKernelGGL(emb_scatter_kernel, dim3(a.n_rm + a.n_cat + a.n_tr + a.n_user + 1), dim3(SCATTER_THREADS), 0,
                      static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("emb_scatter");
   return MTAM_OK;

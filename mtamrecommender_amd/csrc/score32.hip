@@ -163,16 +163,27 @@ __global__ __launch_bounds__(256) void score32_lse_kernel(const float *__restric
   }
 }
 
+// row0 >= 0 (a ROW RANGE of the catalog, data-parallel row-sharded scoring): E is the range's first row, targets are
+// catalog row numbers; a target outside [row0, row0 + V) has no row here -- its logit comes out 0 -- and `ce` receives
+// the TARGET LOGIT (not lse - logit): the ranks' (lse, logit) pairs are combined by the caller.  row0 < 0: the whole
+// catalog, targets clamped, ce = lse - logit.
+__device__ __forceinline__ int local_target(int t, int row0, int V) {
+  if (row0 < 0) return min(max(t, 0), V - 1);
+  t -= row0;
+  return (t >= 0 && t < V) ? t : -1;
+}
 __global__ __launch_bounds__(256) void score32_finish_kernel(const float *__restrict__ E, const float *__restrict__ P,
                                                              const int32_t *__restrict__ target, int V, int chunks,
                                                              const float *__restrict__ partial,
-                                                             float *__restrict__ lse, float *__restrict__ ce) {
+                                                             float *__restrict__ lse, float *__restrict__ ce,
+                                                             int row0) {
   __shared__ float red[4], red2[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float *pp = partial + (size_t)b * chunks * 2;
   // all loads first: the target row and this row's partials
-  const long t = min(max(target[b], 0), V - 1);
-  float dot = (tid < D) ? P[(size_t)b * D + tid] * E[t * D + tid] : 0.f;
+  const int tl = local_target(target[b], row0, V);
+  const long t = max(tl, 0);
+  float dot = (tid < D && tl >= 0) ? P[(size_t)b * D + tid] * E[t * D + tid] : 0.f;
   float m = -INFINITY;
   for (int c = tid; c < chunks; c += 256) m = fmaxf(m, pp[2 * c]);
   m = wave_max(m);
@@ -192,7 +203,8 @@ __global__ __launch_bounds__(256) void score32_finish_kernel(const float *__rest
   if (tid == 0) {
     const float l = m + logf((red[0] + red[1]) + (red[2] + red[3]));
     lse[b] = l;
-    ce[b] = l - ((red2[0] + red2[1]) + (red2[2] + red2[3]));
+    const float logit = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+    ce[b] = row0 < 0 ? l - logit : logit;
   }
 }
 
@@ -204,6 +216,7 @@ struct BwdArgs {
   int V, Bt, slabs_per_wg;
   float scale;
   float *d_pred, *dE, *sq_partial;
+  int row0;                   // >= 0: E is a row range starting at catalog row row0 (see local_target)
 };
 
 template <bool RMW>
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(256) void score32_bwd_kernel(BwdArgs p) {
   const int brow = min(bcol, p.Bt - 1);
   // a batch row that does not exist gets c_b = -inf and no target: G = 0 without a mask
   const float c_b = valid_b ? fmaf(-p.lse[brow], L2E, log2f(p.scale)) : -INFINITY;
-  const int t_b = valid_b ? min(max(p.target[brow], 0), V - 1) : -1;
+  const int t_b = valid_b ? local_target(p.target[brow], p.row0, V) : -1;
   float p1[64], p2[64];
   load_half_row(p1, p.P + (size_t)brow * D, h);
   // pred[b = s + 64 h][d = dcol]: the k operand of dE (rows past the tile: any valid row, their G is 0)
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(768) void bwd_tr3_kernel(BwdArgs p) {
     const bool valid_b = bcol < p.Bt;
     const int brow = min(bcol, p.Bt - 1);
     const float c_b = valid_b ? fmaf(-p.lse[brow], L2E, log2f(p.scale)) : -INFINITY;
-    const int t_b = valid_b ? min(max(p.target[brow], 0), V - 1) : -1;
+    const int t_b = valid_b ? local_target(p.target[brow], p.row0, V) : -1;
     Tri p1[8];
     load_pred_rows(p1, p.P + (size_t)brow * D, h);
     const int swz_r = ((r & 3) << 2) | ((r >> 2) & 3);
@@ -768,6 +781,11 @@ extern "C" int mtam_score32_sq_partials(int V) { return grid_of(V) * 4; }
 
 extern "C" int mtam_score32_lse(const float *E, const float *pred, const int32_t *target, int B, int V,
                                 float *partial, int n_partial, float *lse, float *ce, void *stream) {
+  return mtam_score32_lse_range(E, pred, target, B, V, -1, partial, n_partial, lse, ce, stream);
+}
+
+extern "C" int mtam_score32_lse_range(const float *E, const float *pred, const int32_t *target, int B, int V, int row0,
+                                      float *partial, int n_partial, float *lse, float *ce, void *stream) {
   MTAM_CHECK_ARG(E && pred && target && partial && lse && ce, "score32_lse: null argument");
   MTAM_CHECK_ARG(B > 0 && V > 0 && n_partial >= mtam_score32_partials(B, V),
                  "score32_lse: partial buffer holds %d floats, this form of the pass writes %d (sized before "
@@ -782,7 +800,7 @@ extern "C" int mtam_score32_lse(const float *E, const float *pred, const int32_t
   else
     hipLaunchKernelGGL(score32_lse_kernel, dim3(grid, (B + BT - 1) / BT), dim3(256), 0, s, E, pred, V, B,
                        lse_slabs_per_wg_of(V), partial);
-  hipLaunchKernelGGL(score32_finish_kernel, dim3(B), dim3(256), 0, s, E, pred, target, V, grid, partial, lse, ce);
+  hipLaunchKernelGGL(score32_finish_kernel, dim3(B), dim3(256), 0, s, E, pred, target, V, grid, partial, lse, ce, row0);
   MTAM_CHECK_LAUNCH("score32_lse");
   return MTAM_OK;
 }
@@ -790,6 +808,12 @@ extern "C" int mtam_score32_lse(const float *E, const float *pred, const int32_t
 extern "C" int mtam_score32_bwd(const float *E, const float *pred, const float *lse, const int32_t *target, int B,
                                 int V, float scale, float *d_pred, float *dE, float *sq_partial, int n_sq_partial,
                                 void *stream) {
+  return mtam_score32_bwd_range(E, pred, lse, target, B, V, -1, scale, d_pred, dE, sq_partial, n_sq_partial, stream);
+}
+
+extern "C" int mtam_score32_bwd_range(const float *E, const float *pred, const float *lse, const int32_t *target, int B,
+                                      int V, int row0, float scale, float *d_pred, float *dE, float *sq_partial,
+                                      int n_sq_partial, void *stream) {
   MTAM_CHECK_ARG(E && pred && lse && target && d_pred && dE, "score32_bwd: null argument");
   MTAM_CHECK_ARG(!sq_partial || (V > 0 && n_sq_partial == mtam_score32_sq_partials(V)),
                  "score32_bwd: sq_partial holds %d floats, this form of the pass writes %d (sized before "
@@ -816,7 +840,7 @@ extern "C" int mtam_score32_bwd(const float *E, const float *pred, const float *
   for (int tile = 0; tile < ntile; ++tile) {
     const long b0 = (long)tile * BT;
     BwdArgs a{E, pred + b0 * D, lse + b0, target + b0, V, (int)min((long)BT, B - b0), slabs_per_wg_of(V), scale,
-              d_pred + b0 * D, dE, tile == ntile - 1 ? sq_partial : nullptr};
+              d_pred + b0 * D, dE, tile == ntile - 1 ? sq_partial : nullptr, row0};
     if (split && tile == 0)
       hipLaunchKernelGGL(x3::bwd_tr3_kernel<false>, dim3(grid_of(V)), dim3(768), x3::TR3_LDS, st, a);
     else if (split)

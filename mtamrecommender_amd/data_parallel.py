@@ -48,21 +48,38 @@ def allreduce_gradients(buffers, group=None):
         dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
 
 
-def attach(path, world_size, group=None, force=False, shard_items=None):
+EXCHANGES = ("flat", "sharded", "sharded-scoring")
+
+
+def attach(path, world_size, group=None, force=False, shard_items=None, exchange=None):
     """Make ``path.train_kernels`` exchange gradients; call once after building the model.
     ``force`` installs the exchange even for one rank (tests the code path on one GPU).
-    ``shard_items``: True / False, or None = by size -- the item table's gradient is exchanged as
-    reduce-scatter + shard-owned update + all-gather (ShardedItemExchange) once it is at least
-    MTAM_DP_SHARD_MIN_BYTES (default 64 MiB); below that one flat all-reduce of every gradient is cheaper."""
+    ``exchange`` (or MTAM_DP_EXCHANGE): "flat" = one all-reduce of every gradient; "sharded" = the item gradient as
+    reduce-scatter + shard-owned update + all-gather (ShardedItemExchange); "sharded-scoring" = the item table
+    row-sharded for scoring too, the dense item gradient never moves (ShardedScoringExchange); None = by size --
+    "sharded" once the item table is at least MTAM_DP_SHARD_MIN_BYTES (default 64 MiB), "flat" below that.
+    ``shard_items`` (True / False): the older spelling of "sharded" / "flat"."""
     if world_size <= 1 and not force:
         return
     path.tf_compat = False
     path.world_size = world_size
-    if shard_items is None:
-        shard_items = path.item_rows * D * 4 >= int(os.environ.get("MTAM_DP_SHARD_MIN_BYTES", str(64 << 20)))
-    if shard_items:
-        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    exchange = exchange or os.environ.get("MTAM_DP_EXCHANGE") or None
+    if exchange is None and shard_items is not None:
+        exchange = "sharded" if shard_items else "flat"
+    if exchange is None:
+        big = path.item_rows * D * 4 >= int(os.environ.get("MTAM_DP_SHARD_MIN_BYTES", str(64 << 20)))
+        exchange = "sharded" if big else "flat"
+    if exchange not in EXCHANGES:
+        raise ValueError("unknown data-parallel exchange %r (one of %s)" % (exchange, ", ".join(EXCHANGES)))
+    path.dp_exchange = exchange
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if exchange == "sharded":
         path.sharded = ShardedItemExchange(path, max(world_size, 1), rank, group)
+        return
+    if exchange == "sharded-scoring":
+        if not path.logits_free32:
+            raise ValueError("sharded-scoring runs on the fp32 logits-free scoring kernels (score_dtype 'f32')")
+        path.sharded_scoring = ShardedScoringExchange(path, max(world_size, 1), rank, group)
         return
 
     # The reported loss is a sum over ranks too (reg * l2 is a plain sum, the cross entropy a mean over the GLOBAL
@@ -142,19 +159,30 @@ class ShardedItemExchange(object):
         dev = path.flat_g.device
         self.sq = torch.zeros(1, dtype=torch.float64, device=dev)
 
-    def _gloo(self):
-        return dist.get_backend(self.group) == "gloo"
+    # ---- the two in-place collectives over the item region (the SAME calls under RCCL and under gloo: this build's
+    # gloo has both, so the 2- and 4-rank CPU tests run exactly these lines)
+    def _item_region(self, flat):
+        item = flat[self.off_item:self.off_item + self.world * self.shard_elems]
+        mine = flat[self.lo:self.hi]
+        # the in-place contract of both collectives: this rank's piece IS piece `rank` of the whole buffer
+        assert self.lo == self.off_item + self.rank * self.shard_elems and self.hi - self.lo == self.shard_elems
+        assert mine.untyped_storage().data_ptr() == item.untyped_storage().data_ptr()
+        assert mine.storage_offset() == item.storage_offset() + self.rank * self.shard_elems
+        assert item.numel() == self.world * mine.numel() and item.is_contiguous() and mine.is_contiguous()
+        return item, mine
+
+    def reduce_scatter_item_gradient(self):
+        item, mine = self._item_region(self.p.flat_g)
+        dist.reduce_scatter_tensor(mine, item, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather_item_rows(self):
+        item, mine = self._item_region(self.p.flat_p)
+        dist.all_gather_into_tensor(item, mine, group=self.group)
 
     def exchange(self):
         p = self.p
         dist.all_reduce(p.flat_g[:self.off_item], op=dist.ReduceOp.SUM, group=self.group)
-        item = p.flat_g[self.off_item:self.off_item + self.world * self.shard_elems]
-        if self._gloo():
-            # the CPU test backend has no reduce-scatter: an all-reduce leaves the same sums on the owned rows
-            dist.all_reduce(item, op=dist.ReduceOp.SUM, group=self.group)
-        else:
-            # in place (RCCL: recvbuff == sendbuff + rank * recvcount)
-            dist.reduce_scatter_tensor(p.flat_g[self.lo:self.hi], item, op=dist.ReduceOp.SUM, group=self.group)
+        self.reduce_scatter_item_gradient()
 
     def apply(self, bt):
         p, k = self.p, self.k
@@ -173,19 +201,144 @@ class ShardedItemExchange(object):
         if self.hi_true > self.lo:
             k.adam(p.flat_p[self.lo:self.hi_true], p.flat_m[self.lo:self.hi_true], p.flat_v[self.lo:self.hi_true],
                    p.flat_g[self.lo:self.hi_true], p.scale, p.adam_state, 0)
-        item = p.flat_p[self.off_item:self.off_item + self.world * self.shard_elems]
-        if self._gloo():
-            mine = p.flat_p[self.lo:self.hi].clone()
-            dist.all_gather([item[r * self.shard_elems:(r + 1) * self.shard_elems] for r in range(self.world)], mine,
-                            group=self.group)
-        else:
-            dist.all_gather_into_tensor(item, p.flat_p[self.lo:self.hi], group=self.group)      # in place
+        self.all_gather_item_rows()
         p.refresh_derived()
 
     def exchange_and_apply(self, bt):
         if self.p.optimizer != "adam":
             raise NotImplementedError("the row-sharded exchange is built for Adam (the reference's default optimizer)")
         self.exchange()
+        self.apply(bt)
+
+
+class HipScoringKernels(HipStepKernels):
+    """The scoring-side kernels ShardedScoringExchange drives, on a ROW RANGE of the item table (csrc/score32.hip,
+    csrc/emb.hip through the C ABI); a CPU twin stands in for them in the gloo tests."""
+
+    def __init__(self, path):
+        super(HipScoringKernels, self).__init__(path)
+        self._partials = {}
+
+    def _bufs(self, Bg, V):
+        key = (Bg, V)
+        if key not in self._partials:
+            dev = self.p.device
+            self._partials[key] = (torch.zeros(self.ops.score32_partials(Bg, V), device=dev),
+                                   torch.zeros(self.ops.score32_sq_partials(V), device=dev))
+        return self._partials[key]
+
+    def lse_range(self, E_rows, row0, pred_all, tgt_all, lse_part, tlogit):
+        Bg, V = pred_all.shape[0], E_rows.shape[0]
+        self.ops.score32_lse(E_rows, pred_all, tgt_all, Bg, V, self._bufs(Bg, V)[0], lse_part, tlogit, row0=row0)
+
+    def bwd_range(self, E_rows, row0, pred_all, lse_all, tgt_all, scale, d_pred_all, dE_rows):
+        Bg, V = pred_all.shape[0], E_rows.shape[0]
+        d_pred_all.zero_()
+        self.ops.score32_bwd(E_rows, pred_all, lse_all, tgt_all, Bg, V, scale, d_pred_all, dE_rows, None, row0=row0)
+
+    def scatter_items(self, d_ic, ic, item_ids, seq_len, B, L, reg, g_item, rows):
+        n = self.ops.emb_scatter_partials(B, L)
+        if getattr(self, "_slot_sq", None) is None or self._slot_sq.numel() < n:
+            self._slot_sq = torch.zeros(n, device=self.p.device)
+        self.ops.emb_scatter_add_items_range(d_ic, ic, item_ids, seq_len, B, L, reg, g_item, self._slot_sq, rows)
+
+
+class ShardedScoringExchange(ShardedItemExchange):
+    """Data parallelism with the item table ROW-SHARDED FOR SCORING as well ("alternative worth
+    measuring"; Model/base_model.py:309-322 is the product being distributed).
+
+    Under ShardedItemExchange every rank scores the whole catalog for its own samples, so every rank holds a dense
+    [V, 128] item gradient and the ranks exchange it (reduce-scatter: 4.5 GB per rank at 10 M items, then as much
+    again for the all-gather of the updated rows).  Here a rank scores only the rows it OWNS, for the samples of
+    EVERY rank:
+
+      forward (graph)   lookups .. decoder -> pred [B, 128] of the rank's own samples
+      all-gather        pred -> [G B, 128], target ids -> [G B]                                   (0.5 MB at G = 8)
+      lse pass          own rows x all samples -> per-sample log-sum-exp over the range + target logit if owned
+      all-reduce        max, then (sum of exp, target logit): the whole catalog's lse and the loss terms  (8 KB)
+      backward pass     own rows x all samples: dE of the own rows -- COMPLETE, nothing to exchange -- and the range's
+                        share of d_pred for all samples
+      reduce-scatter    d_pred shares -> the rank's own samples                                    (0.5 MB)
+      backward (graph)  decoder .. lookups from d_pred; the scatter-add applies the rank's history-row gradients to
+                        its OWN item rows only
+      all-gather        every rank's history slots (d[item|category] rows, looked-up rows, ids, lengths: 13 MB per
+                        rank); each rank applies the other ranks' slots that fall into its rows
+      then as ShardedItemExchange: all-reduce of the small gradients, clip from owned squares, Adam on the owned rows,
+      all-gather of the updated rows (history lookups read a replicated table).
+
+    Wire volume per rank at 10 M items, 8 ranks: 4.5 GB (the updated rows) instead of 9 GB; the dense item gradient is
+    never moved.  Arithmetic is the replicated exchange's: the same products, each sample's softmax over the same
+    rows -- sums in a different order (the lse combines per-rank partial sums), so equality is to fp32 rounding, not
+    bit for bit.  No run with more than one GPU exists yet: 2- and 4-rank gloo tests on CPU tensors against the
+    replicated update, a 1-rank RCCL test through the real kernels against the single-GPU step.
+    """
+
+    def __init__(self, path, world, rank, group=None, kernels=None):
+        super(ShardedScoringExchange, self).__init__(path, world, rank, group,
+                                                     kernels if kernels is not None else HipScoringKernels(path))
+        self.rows_per_rank = path.item_rows_pad // world
+        self.row_lo = rank * self.rows_per_rank
+        self.row_hi = max(self.row_lo, min(self.row_lo + self.rows_per_rank, path.item_rows))   # rows that exist
+        if self.row_hi <= self.row_lo:
+            raise ValueError("rank %d owns no item row (%d rows over %d ranks)" % (rank, path.item_rows, world))
+        self._b = {}
+
+    def _buffers(self, bt):
+        B = bt.B
+        if B not in self._b:
+            G, dev = self.world, bt.pred.device
+            f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+            R = bt.ic.shape[0]
+            self._b[B] = dict(pred=f(G * B, D), tgt=torch.zeros(G * B, dtype=torch.int32, device=dev), lse_part=f(G * B),
+                              stats=f(2, G * B), lse=f(G * B), d_pred=f(G * B, D),
+                              d_ic=f(G, R, 2 * D), ic=f(G, R, 2 * D),
+                              ids=torch.zeros((G, R), dtype=torch.int32, device=dev),
+                              sl=torch.zeros((G, B), dtype=torch.int32, device=dev))
+        return self._b[B]
+
+    # ---- between the two halves of the step
+    def score(self, bt):
+        """bt.pred (own samples) -> bt.lse, bt.ce (own samples), bt.d_pred (own samples), dE of the own item rows."""
+        p, k, w = self.p, self.k, self._buffers(bt)
+        B, G, r = bt.B, self.world, self.rank
+        dist.all_gather_into_tensor(w["pred"], bt.pred, group=self.group)
+        dist.all_gather_into_tensor(w["tgt"], bt.feed["target_item_id"], group=self.group)
+        E_rows = p.tables["item"][self.row_lo:self.row_hi]
+        lse_part, tlogit = w["lse_part"], w["stats"][1]
+        k.lse_range(E_rows, self.row_lo, w["pred"], w["tgt"], lse_part, tlogit)
+        # the whole catalog's log-sum-exp: m = max_r lse_r, lse = m + log sum_r exp(lse_r - m); the target's logit
+        # lives on exactly one rank
+        m = lse_part.clone()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+        torch.exp(lse_part - m, out=w["stats"][0])
+        dist.all_reduce(w["stats"], op=dist.ReduceOp.SUM, group=self.group)
+        torch.add(m, torch.log(w["stats"][0]), out=w["lse"])
+        own = slice(r * B, (r + 1) * B)
+        bt.lse.copy_(w["lse"][own])
+        bt.ce.copy_(w["lse"][own] - w["stats"][1][own])
+        dE_rows = p.g_tab["item"][self.row_lo:self.row_hi]
+        k.bwd_range(E_rows, self.row_lo, w["pred"], w["lse"], w["tgt"], 1.0 / p.gb(bt), w["d_pred"], dE_rows)
+        dist.reduce_scatter_tensor(bt.d_pred, w["d_pred"], op=dist.ReduceOp.SUM, group=self.group)
+
+    # ---- after the backward
+    def exchange(self, bt):
+        p, k, w = self.p, self.k, self._buffers(bt)
+        dist.all_reduce(p.flat_g[:self.off_item], op=dist.ReduceOp.SUM, group=self.group)
+        # every rank's history slots; the other ranks' slots that fall into this rank's rows are added to them
+        # (outputs as the concatenation along dim 0 of the ranks' inputs: the shape both backends accept)
+        dist.all_gather_into_tensor(w["d_ic"].view(-1, 2 * D), bt.d_ic, group=self.group)
+        dist.all_gather_into_tensor(w["ic"].view(-1, 2 * D), bt.ic, group=self.group)
+        dist.all_gather_into_tensor(w["ids"].view(-1), bt.feed["item_list"].reshape(-1), group=self.group)
+        dist.all_gather_into_tensor(w["sl"].view(-1), bt.feed["seq_length"], group=self.group)
+        for src in range(self.world):
+            if src != self.rank:
+                k.scatter_items(w["d_ic"][src], w["ic"][src], w["ids"][src], w["sl"][src], bt.B, p.L, p.reg,
+                                p.g_tab["item"], (self.row_lo, self.row_hi))
+
+    def exchange_and_apply(self, bt):
+        if self.p.optimizer != "adam":
+            raise NotImplementedError("the row-sharded exchange is built for Adam (the reference's default optimizer)")
+        self.exchange(bt)
         self.apply(bt)
 
 

@@ -132,11 +132,20 @@ def emb_scatter_partials(B, L):
 
 def emb_scatter_add_bwd(d_ic, d_pos, ic, pos, user, item_ids, cat_ids, pos_ids, user_ids, seq_len, B, L,
                         reg, with_user, g_item, g_cat, g_pos, g_user, slot_sq_partial, pos_table=None, d_z=None,
-                        W4=None):
+                        W4=None, item_range=None):
     """pos_table given (and pos None): the looked-up position rows were never written out; their L2 term reads
     the table through the ids (steps whose forward is seq_chain_gather_fwd).  d_z and W4 given (and d_ic None): the
-    [item | category] gradient rows are computed inside the kernel, d_z . W4^T per 128-slot chunk."""
+    [item | category] gradient rows are computed inside the kernel, d_z . W4^T per 128-slot chunk.
+    item_range = (lo, hi): only item slots with lo <= id < hi are added (a data-parallel rank's own item rows)."""
     lib = _lib.load()
+    if item_range is not None:
+        rc = lib.mtam_emb_scatter_add_bwd_range(
+            _p(d_ic), _p(d_z), _p(W4), _p(d_pos), _p(ic), _p(pos), _p(pos_table), _p(user), _pi(item_ids),
+            _pi(cat_ids), _pi(pos_ids), _pi(user_ids), _pi(seq_len), B, L, float(reg), int(with_user), _p(g_item),
+            g_item.shape[0], _p(g_cat), g_cat.shape[0], _p(g_pos), g_pos.shape[0], _p(g_user), g_user.shape[0],
+            _p(slot_sq_partial), int(item_range[0]), int(item_range[1]), 0, _stream())
+        _lib.check(rc, "mtam_emb_scatter_add_bwd_range")
+        return
     if d_z is not None:
         rc = lib.mtam_emb_scatter_add_bwd_fused(
             _p(d_ic), _p(d_z), _p(W4), _p(d_pos), _p(ic), _p(pos), _p(pos_table), _p(user), _pi(item_ids),
@@ -158,6 +167,16 @@ def emb_scatter_add_bwd(d_ic, d_pos, ic, pos, user, item_ids, cat_ids, pos_ids, 
                                       g_cat.shape[0], _p(g_pos), g_pos.shape[0], _p(g_user),
                                       g_user.shape[0], _p(slot_sq_partial), _stream())
     _lib.check(rc, "mtam_emb_scatter_add_bwd")
+
+
+def emb_scatter_add_items_range(d_ic, ic, item_ids, seq_len, B, L, reg, g_item, slot_sq_partial, item_range):
+    """Another rank's slots (its all-gathered d[item | category] rows, looked-up rows, item ids, lengths) applied to
+    THIS rank's item rows [lo, hi) of the item gradient -- only the item halves are read."""
+    rc = _lib.load().mtam_emb_scatter_add_bwd_range(
+        _p(d_ic), None, None, None, _p(ic), None, None, None, _pi(item_ids), None, None, None, _pi(seq_len), B, L,
+        float(reg), 0, _p(g_item), g_item.shape[0], None, 1, None, 1, None, 1, _p(slot_sq_partial),
+        int(item_range[0]), int(item_range[1]), 1, _stream())
+    _lib.check(rc, "mtam_emb_scatter_add_bwd_range")
 
 
 def tagru_fwd(xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save):
@@ -465,17 +484,21 @@ def score32_sq_partials(V):
     return _lib.load().mtam_score32_sq_partials(V)
 
 
-def score32_lse(E, pred, target, B, V, partial, lse, ce):
+def score32_lse(E, pred, target, B, V, partial, lse, ce, row0=None):
+    """row0 given: E is a row RANGE of the catalog starting at catalog row row0 (V rows); ``target`` holds catalog
+    row numbers; lse = log-sum-exp over the range, ce = the target's logit (0 when the target is not in the range)."""
     lib = _lib.load()
-    _lib.check(lib.mtam_score32_lse(_p(E), _p(pred), _pi(target), B, V, _p(partial), partial.numel(), _p(lse), _p(ce),
-                                    _stream()), "mtam_score32_lse")
+    _lib.check(lib.mtam_score32_lse_range(_p(E), _p(pred), _pi(target), B, V, -1 if row0 is None else int(row0),
+                                          _p(partial), partial.numel(), _p(lse), _p(ce), _stream()), "mtam_score32_lse")
 
 
-def score32_bwd(E, pred, lse, target, B, V, scale, d_pred, dE, sq_partial=None, n_sq=None):
+def score32_bwd(E, pred, lse, target, B, V, scale, d_pred, dE, sq_partial=None, n_sq=None, row0=None):
     lib = _lib.load()
-    _lib.check(lib.mtam_score32_bwd(_p(E), _p(pred), _p(lse), _pi(target), B, V, float(scale), _p(d_pred), _p(dE),
-                                    _p(sq_partial), 0 if sq_partial is None else
-                                    (sq_partial.numel() if n_sq is None else int(n_sq)), _stream()), "mtam_score32_bwd")
+    _lib.check(lib.mtam_score32_bwd_range(_p(E), _p(pred), _p(lse), _pi(target), B, V,
+                                          -1 if row0 is None else int(row0), float(scale), _p(d_pred), _p(dE),
+                                          _p(sq_partial), 0 if sq_partial is None else
+                                          (sq_partial.numel() if n_sq is None else int(n_sq)), _stream()),
+               "mtam_score32_bwd")
 
 
 def score16_logits(E16, P16, B, V, logits, ld):

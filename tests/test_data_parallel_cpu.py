@@ -187,3 +187,165 @@ def test_sharded_item_exchange_equals_the_replicated_update(tmp_path, world):
         assert rel < 1e-7 and same == 1.0 and same_slots == 1.0 and pad_zero == 1.0, (rank, rel, same, same_slots)
         assert abs(dloss) < 1e-5 and refreshed == 1.0
         assert same_scale == 1.0            # the clip scale itself came out bit-identical too
+
+
+# ------------------------------------------------- item table row-sharded for SCORING as well (SURVEY.md 8e alternative)
+class _TorchScoringKernels(_TorchStepKernels):
+    """CPU twin of data_parallel.HipScoringKernels: the two scoring passes over a row range and the item-only
+    scatter-add of another rank's slots, with torch ops."""
+
+    def lse_range(self, E_rows, row0, pred_all, tgt_all, lse_part, tlogit):
+        logits = pred_all @ E_rows.t()
+        lse_part.copy_(torch.logsumexp(logits, 1))
+        t = tgt_all.long() - row0
+        owned = (t >= 0) & (t < E_rows.shape[0])
+        tlogit.copy_(torch.where(owned, logits.gather(1, t.clamp(0, E_rows.shape[0] - 1)[:, None])[:, 0],
+                                 torch.zeros_like(lse_part)))
+
+    def bwd_range(self, E_rows, row0, pred_all, lse_all, tgt_all, scale, d_pred_all, dE_rows):
+        G = torch.exp(pred_all @ E_rows.t() - lse_all[:, None])
+        t = tgt_all.long() - row0
+        owned = (t >= 0) & (t < E_rows.shape[0])
+        G[torch.nonzero(owned)[:, 0], t[owned]] -= 1.0
+        G *= scale
+        d_pred_all.copy_(G @ E_rows)
+        dE_rows.copy_(G.t() @ pred_all)
+
+    def scatter_items(self, d_ic, ic, item_ids, seq_len, B, L, reg, g_item, rows):
+        D = 128
+        live = (torch.arange(L)[None, :] < seq_len[:, None]).reshape(-1)
+        g = torch.where(live[:, None], d_ic[:, :D], torch.zeros(1)) + reg * ic[:, :D]      # padded slots: the L2 term only
+        ids = item_ids.long()
+        mine = (ids >= rows[0]) & (ids < rows[1])
+        g_item.index_add_(0, ids[mine], g[mine])
+
+
+class _ToyBatch(object):
+    pass
+
+
+def _toy_inputs(rank, B, L, V, seed=7):
+    g = torch.Generator().manual_seed(seed * 100 + rank)
+    sl = torch.randint(1, L + 1, (B,), generator=g, dtype=torch.int32)
+    ids = torch.randint(0, V, (B, L), generator=g, dtype=torch.int32)
+    ids = torch.where(torch.arange(L)[None, :] < sl[:, None], ids, torch.zeros_like(ids))     # the feed pads with id 0
+    ids[0, 0] = V - 1                                                                          # the last rank's last row
+    tgt = torch.randint(0, V, (B,), generator=g, dtype=torch.int32)
+    return ids, sl, tgt
+
+
+def _toy_loss(E, W, ids, sl, tgt, reg, global_batch):
+    """pred_b = tanh(sum_{t < len_b} E[id_bt] . W); cross entropy over the whole catalog (a mean over the GLOBAL
+    batch) + reg * 1/2 sum over ALL slots of |E[id]|^2 -- the shape of Model/base_model.py:300-328."""
+    L = ids.shape[1]
+    rows = E[ids.long()]
+    live = (torch.arange(L)[None, :] < sl[:, None]).to(E.dtype)
+    pred = torch.tanh((rows * live[:, :, None]).sum(1) @ W)
+    logits = pred @ E.t()
+    ce = torch.logsumexp(logits, 1) - logits.gather(1, tgt.long()[:, None])[:, 0]
+    return ce.sum() / global_batch + reg * 0.5 * (rows ** 2).sum(), pred, ce
+
+
+def _scoring_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from mtamrecommender_amd import data_parallel
+    D, B, L, V = 128, 5, 4, 203
+    # the same replica on every rank: a [D, D] dense matrix at the head of the flat space, 37 small-table rows whose
+    # gradient is random per rank (they only ride the small all-reduce), the item table
+    path = _FakePath(n_dense=D * D, small_rows=37, item_rows=V, seed=1)
+    path.world_size, path.L = world, L
+    off = path.tab_off["item"]
+    path.tables = {"item": path.flat_p[off:off + V * D].view(V, D)}
+    path.g_tab = {"item": path.flat_g[off:off + V * D].view(V, D)}
+    ref = _FakePath(n_dense=D * D, small_rows=37, item_rows=V, seed=1)
+    ref.world_size = world
+    small = slice(D * D, off)
+    gens = [torch.Generator().manual_seed(500 + r) for r in range(world)]
+    small_g = [torch.round(torch.randn(off - D * D, generator=g) * 0.02 * 4096) / 4096 for g in gens]
+    k = _TorchScoringKernels()
+    lr = torch.tensor([1e-3])
+
+    # ---- the replicated update: the whole batch on one replica
+    E0 = ref.flat_p[off:off + V * D].view(V, D).clone().requires_grad_(True)
+    W0 = ref.flat_p[:D * D].view(D, D).clone().requires_grad_(True)
+    every = [_toy_inputs(r, B, L, V) for r in range(world)]
+    ids_all, sl_all, tgt_all = (torch.cat([e[i] for e in every]) for i in range(3))
+    loss_ref, _, ce_ref = _toy_loss(E0, W0, ids_all, sl_all, tgt_all, ref.reg, world * B)
+    loss_ref.backward()
+    ref.flat_g[:D * D] = W0.grad.reshape(-1)
+    ref.flat_g[small] = sum(small_g)
+    ref.flat_g[off:off + V * D] = E0.grad.reshape(-1)
+    sq = torch.zeros(1, dtype=torch.float64)
+    k.sq_sum(ref.flat_g[:ref.n_total], 1.0, sq, False)
+    k.clip_scale(sq, ref.clip, ref.scale, lr, ref.adam_state)
+    k.adam(ref.flat_p[:ref.n_total], ref.flat_m[:ref.n_total], ref.flat_v[:ref.n_total], ref.flat_g[:ref.n_total],
+           ref.scale, ref.adam_state, ref.n_dense)
+
+    # ---- the row-sharded step on this rank's slice of the batch
+    ex = data_parallel.ShardedScoringExchange(path, world, rank, kernels=k)
+    assert ex.row_lo == rank * (path.item_rows_pad // world) and ex.row_hi <= V
+    ids, sl, tgt = every[rank]
+    bt = _ToyBatch()
+    bt.B = B
+    bt.feed = {"lr": lr, "target_item_id": tgt, "item_list": ids, "seq_length": sl}
+    bt.loss, bt.lse, bt.ce, bt.d_pred = torch.zeros(3), torch.zeros(B), torch.zeros(B), torch.zeros(B, D)
+    # forward to pred (the part of the step before the scoring passes)
+    E = path.tables["item"].clone().requires_grad_(True)
+    W = path.flat_p[:D * D].view(D, D).clone().requires_grad_(True)
+    rows = E[ids.long()]
+    live = (torch.arange(L)[None, :] < sl[:, None]).float()
+    pred = torch.tanh((rows * live[:, :, None]).sum(1) @ W)
+    bt.pred = pred.detach().clone()
+    bt.ic = torch.cat([rows.detach().reshape(B * L, D), torch.zeros(B * L, D)], 1).contiguous()
+    ex.score(bt)
+    # backward from d_pred: dense gradient, the looked-up rows' gradients, the rank's own slots into its own rows
+    pred.backward(bt.d_pred)
+    path.flat_g[:D * D] = W.grad.reshape(-1)
+    path.flat_g[small] = small_g[rank]
+    # (E.grad is dense here only because autograd has no other way to hand the looked-up rows' gradient over)
+    d_rows = torch.zeros(B * L, D)
+    flat_ids = ids.reshape(-1).long()
+    seen = {}
+    for slot in range(B * L):                      # one slot per id carries the id's whole (summed) gradient
+        i = int(flat_ids[slot])
+        if bool(live.reshape(-1)[slot]) and i not in seen:
+            seen[i] = slot
+            d_rows[slot] = E.grad[i]
+    bt.d_ic = torch.cat([d_rows, torch.zeros(B * L, D)], 1).contiguous()
+    bt.l2 = 0.5 * float((rows.detach() ** 2).sum())            # tf.nn.l2_loss: half the sum of squares
+    k.scatter_items(bt.d_ic, bt.ic, ids.reshape(-1), sl, B, L, path.reg, path.g_tab["item"], (ex.row_lo, ex.row_hi))
+    ex.exchange_and_apply(bt)
+
+    own = slice(ex.lo, ex.hi_true)
+    err = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    res = [err(path.flat_p[:path.n_total], ref.flat_p[:ref.n_total]), err(path.flat_m[own], ref.flat_m[own]),
+           err(path.flat_v[own], ref.flat_v[own]), err(path.flat_m[:off], ref.flat_m[:off]),
+           abs(float(path.scale[1]) - float(ref.scale[1])) / float(ref.scale[1]),
+           abs(float(bt.loss[0]) - float(loss_ref.detach())) / float(loss_ref.detach()),
+           err(bt.ce, ce_ref[rank * B:(rank + 1) * B].detach()),
+           float(not bool(path.flat_p[path.n_total:].any())), float(path.refreshed)]
+    np.save(os.path.join(out_dir, "scoring_%d.npy" % rank), np.array(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_scoring_exchange_equals_the_replicated_update(tmp_path, world):
+    """Item table row-sharded for scoring: all-gather pred, every rank scores its own rows for the samples of every
+    rank, the (max, sum-exp, target logit) triples and the d_pred shares are reduced, dE is born sharded, the other
+    ranks' history slots are all-gathered and applied to the owned rows -- against ONE replica doing the whole batch
+    (autograd over the full-catalog softmax + L2, clip, dense Adam): parameters and both slots to fp32 rounding
+    (the sums run in a different order: per-rank partial log-sum-exps), the clip norm, the loss and the per-sample
+    cross entropies; 203 item rows over 2 and 4 ranks (pad rows untouched), the same in-place collectives as RCCL."""
+    port = 29500 + (os.getpid() % 2000) + 11 * world
+    mp.spawn(_scoring_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        p_err, m_err, v_err, ms_err, norm_err, loss_err, ce_err, pad_zero, refreshed = np.load(
+            os.path.join(str(tmp_path), "scoring_%d.npy" % rank))
+        assert p_err < 2e-6 and m_err < 2e-5 and v_err < 2e-5 and ms_err < 2e-5, (rank, p_err, m_err, v_err, ms_err)
+        assert norm_err < 1e-6 and loss_err < 1e-6 and ce_err < 1e-5, (rank, norm_err, loss_err, ce_err)
+        assert pad_zero == 1.0 and refreshed == 1.0

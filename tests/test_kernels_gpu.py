@@ -282,6 +282,42 @@ def test_emb_scatter_add_fused_sources(ops, B, L, with_user):
     assert abs(float(part.double().sum()) - float(part_ref.double().sum())) < 1e-5 * float(part_ref.double().sum())
 
 
+def test_emb_scatter_item_row_ranges(ops):
+    """mtam_emb_scatter_add_bwd_range (data-parallel row-sharded scoring): with the item rows cut into ranges, the
+    ranges' scatter-adds -- the owner's full call restricted to its rows, and the item-only form that applies ANOTHER
+    rank's slots -- add up to the one-piece scatter-add, item table and the other three alike."""
+    rng = np.random.default_rng(3)
+    B, L, V, C, U = 37, 11, 301, 13, 29
+    R = B * L
+    f = lambda *s: dev(rng.standard_normal(s).astype(np.float32))
+    sl = rng.integers(1, L + 1, B)
+    live = np.arange(L)[None, :] < sl[:, None]
+    ids = {k: dev((rng.integers(0, n, (B, L)) * live).astype(np.int32)) for k, n in (("item", V), ("cat", C), ("pos", L + 3))}
+    ids["item"][0, 0] = V - 1
+    user = dev(rng.integers(0, U, B).astype(np.int32))
+    sl_d = dev(sl.astype(np.int32))
+    d_ic, d_x, ic, pos, usr = f(R, 2 * D), f(R, D), f(R, 2 * D), f(R, D), f(B, D)
+    d_ic[~dev(live.reshape(-1))] = 0.0                       # padded slots carry a zero upstream gradient
+    g = lambda: [torch.zeros((n, D), device="cuda") for n in (V, C, L + 3, U)]
+    part = lambda: torch.zeros(ops.emb_scatter_partials(B, L), device="cuda")
+    whole = g()
+    ops.emb_scatter_add_bwd(d_ic, d_x, ic, pos, usr, ids["item"], ids["cat"], ids["pos"], user, sl_d, B, L, 5e-3, 1,
+                            *whole, part())
+    cuts = (0, 104, 208, V)
+    own = g()                                               # "rank 0": every table, its own item rows
+    ops.emb_scatter_add_bwd(d_ic, d_x, ic, pos, usr, ids["item"], ids["cat"], ids["pos"], user, sl_d, B, L, 5e-3, 1,
+                            *own, part(), item_range=(cuts[0], cuts[1]))
+    assert not bool(own[0][cuts[1]:].any())
+    for t in (1, 2, 3):
+        assert float((own[t] - whole[t]).abs().max()) <= 1e-5 * float(whole[t].abs().max())
+    for lo, hi in zip(cuts[1:-1], cuts[2:]):                # "ranks 1, 2": the same slots, item rows only
+        before = own[0].clone()
+        ops.emb_scatter_add_items_range(d_ic, ic, ids["item"].reshape(-1), sl_d, B, L, 5e-3, own[0], part(), (lo, hi))
+        changed = (own[0] != before).any(1)
+        assert not bool(changed[:lo].any()) and not bool(changed[hi:].any())
+    assert float((own[0] - whole[0]).abs().max()) <= 1e-5 * float(whole[0].abs().max())
+
+
 # ------------------------------------------------------------------- GRU
 # Variable names come from the oracle's own tables (oracle/family.py, oracle/specs.py), not from the product's;
 # the ROW ORDER of the packed kernel operands is the C ABI's (include/mtam_hip.h: tvec [8, D], tparams [5, L]).
@@ -906,6 +942,51 @@ def test_score32_lse_and_backward(ops, B, V, form):
         _score32_case(ops, B, V, form)
     finally:
         ops.score32_set_split_min_rows(1)
+
+
+@pytest.mark.parametrize("B,V,cuts", [(128, 3709, (0, 1240, 2480, 3709)), (300, 70007, (0, 8751, 70007)),
+                                      (37, 1003, (0, 126, 252, 378, 504, 630, 756, 882, 1003))])
+def test_score32_row_ranges_combine_to_the_whole_catalog(ops, B, V, cuts):
+    """mtam_score32_lse_range / mtam_score32_bwd_range (data-parallel row-sharded scoring): the catalog cut into row
+    ranges, each scored on its own -- per-range (lse, target logit) combine to the whole catalog's lse / cross entropy,
+    the ranges' dE blocks ARE the rows of the whole dE (complete, nothing to sum) and the ranges' d_pred shares add
+    up to the whole d_pred.  Against the one-piece kernels (fp32 rounding) and float64."""
+    rng = np.random.default_rng(B + V)
+    E = dev((rng.standard_normal((V, D)) * 0.2).astype(np.float32))
+    P = dev(rng.standard_normal((B, D)).astype(np.float32))
+    target = rng.integers(0, V, B).astype(np.int32)
+    target[0], target[1 % B] = V - 1, cuts[1]              # the last row; the first row of the second range
+    tgt = dev(target)
+    z = lambda *s: torch.zeros(s, device="cuda")
+    lse_w, ce_w = z(B), z(B)
+    ops.score32_lse(E, P, tgt, B, V, z(ops.score32_partials(B, V)), lse_w, ce_w)
+    parts, logit = [], z(B)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        lp, tl = z(B), z(B)
+        ops.score32_lse(E[lo:hi], P, tgt, B, hi - lo, z(ops.score32_partials(B, hi - lo)), lp, tl, row0=lo)
+        owned = (tgt >= lo) & (tgt < hi)
+        assert not bool(tl[~owned].any())                   # a target outside the range contributes no logit
+        parts.append(lp)
+        logit += tl
+    lse = torch.logsumexp(torch.stack(parts), 0)
+    ref = torch.logsumexp(P.double() @ E.double().T, 1)
+    assert float((lse.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    assert float((lse - lse_w).abs().max()) < 2e-6 * float(lse_w.abs().max())
+    assert float(((lse - logit) - ce_w).abs().max()) < 2e-5 * float(lse_w.abs().max())
+    # backward: the whole catalog in one piece, then range by range with the combined lse
+    scale = 1.0 / B
+    d_pred_w, dE_w = z(B, D), z(V, D)
+    ops.score32_bwd(E, P, lse, tgt, B, V, scale, d_pred_w, dE_w)
+    d_pred, dE = z(B, D), torch.full((V, D), 9.0, device="cuda")
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        share = z(B, D)
+        ops.score32_bwd(E[lo:hi], P, lse, tgt, B, hi - lo, scale, share, dE[lo:hi], row0=lo)
+        d_pred += share
+    assert float((dE - dE_w).abs().max()) <= 2e-6 * float(dE_w.abs().max())
+    assert float((d_pred - d_pred_w).abs().max()) <= 1e-5 * float(d_pred_w.abs().max())
+    G = torch.exp(P.double() @ E.double().T - ref[:, None])
+    G[torch.arange(B), tgt.long()] -= 1.0
+    assert float((dE.double() - (G * scale).T @ P.double()).abs().max()) < 2e-5 * float(dE_w.abs().max())
 
 
 def test_score32_rejects_buffers_sized_under_the_other_form(ops):
