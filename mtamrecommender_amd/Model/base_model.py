@@ -238,13 +238,14 @@ class base_model(object):
             p.adam_state.copy_(st)
 
     # ------------------------------------------------------------------ step
-    def _run(self, kind, bt, fn, **graph_kw):
-        """Eager on first use of a batch size, then one hipGraph replay per step."""
+    def _run(self, kind, bt, fn, key_extra=(), **graph_kw):
+        """Eager on first use of a batch size, then one hipGraph replay per step.  ``key_extra``: whatever else the
+        captured launches bake in (the pinned arena a feed copy reads, the pinned slot a loss copy writes)."""
         if not self.use_graph:
             fn(bt)
             return
         # the global batch (data parallel: 1 / gb is a kernel argument) is part of what a captured step bakes in
-        key = (kind, bt.B, getattr(self.path, "global_batch", None))
+        key = (kind, bt.B, getattr(self.path, "global_batch", None)) + tuple(key_extra)
         g = self._graphs.get(key)
         if g is None:
             if self._graphs.get(key + ("warm",)) is None:
@@ -327,53 +328,102 @@ class base_model(object):
         With ``async_loss`` the pair belongs to the PREVIOUS step (``summary["loss_step"]`` / ``self.loss_step`` say
         which ``global_step``); the first call returns ``(nan, {"loss_step": None})`` -- nothing has finished yet --
         and ``drain_loss()`` hands over the most recent step's once the loop ends (or before a checkpoint)."""
-        bt, _ = self._load(batch_data, learning_rate)
-        self.step_train(bt)
-        if self.async_loss:
-            loss, step, lr = self._loss_one_step_late(bt, global_step, learning_rate)
-            if loss is None:
-                self.loss_step = None
-                return float("nan"), {"loss_step": None}
+        if self._feed_in_graph(batch_data):
+            bt, loss, step, lr = self._train_feed_in_graph(batch_data, learning_rate, global_step)
         else:
-            loss, step, lr = bt.loss.cpu().numpy(), global_step, learning_rate
+            bt, _ = self._load(batch_data, learning_rate)
+            self.step_train(bt)
+            if self.async_loss:
+                cur = self._loss_begin()
+                self._loss_ring[cur][0].copy_(bt.loss, non_blocking=True)
+                loss, step, lr = self._loss_end(cur, global_step, learning_rate)
+            else:
+                loss, step, lr = bt.loss.cpu().numpy(), global_step, learning_rate
+        if loss is None:
+            self.loss_step = None
+            return float("nan"), {"loss_step": None}
         self.loss_step = step
         return float(loss[0]), self._summary(loss, lr, step)
+
+    # ---- the feed copy (and the loss copy) INSIDE the step's hipGraph
+    def _feed_in_graph(self, batch_data):
+        """A PackedBatch sits in one of its stream's three pinned arenas (DataHandle/native_input.py): the host ->
+        device copy of the feed can be the FIRST NODE of the captured step -- one graph per arena address -- and the
+        device -> host copy of the loss its last (``async_loss``), so that a step is ONE hipGraphLaunch instead of
+        copy + launch + copy back to back on the stream (profiles/r02_host_loop_cprofile.txt: ~25 us of copies and
+        gaps per step).  Single-GPU steps only; MTAM_FEED_IN_GRAPH=0 keeps the copies outside."""
+        from ..DataHandle.native_input import PackedBatch
+        p = self.path
+        return (self.use_graph and isinstance(batch_data, PackedBatch) and p.allreduce_fn is None and
+                p.sharded is None and p.sharded_scoring is None and
+                os.environ.get("MTAM_FEED_IN_GRAPH", "1") != "0")
+
+    def _train_feed_in_graph(self, batch_data, learning_rate, global_step):
+        p = self.path
+        bt = p.batch(batch_data.B)
+        lr_off = bt.offsets["lr"][0]
+        batch_data.arena[lr_off:lr_off + 1].view(torch.float32)[0] = float(np.float32(learning_rate))
+        src = batch_data.arena
+        cur = self._loss_begin() if self.async_loss else -1
+        host = self._loss_ring[cur][0] if cur >= 0 else None
+
+        def fn(bt_):
+            bt_.arena.copy_(src, non_blocking=True)
+            p.train_kernels(bt_)
+            if host is not None:
+                host.copy_(bt_.loss, non_blocking=True)
+
+        self._run("train_feed", bt, fn, key_extra=(src.data_ptr(), cur))
+        if cur >= 0:
+            return (bt,) + self._loss_end(cur, global_step, learning_rate)
+        return bt, bt.loss.cpu().numpy(), global_step, learning_rate
 
     @staticmethod
     def _summary(loss, learning_rate, step):
         return {"normalized Training Loss": float(loss[0]), "l2_norm": float(loss[1]),
                 "Training Loss": float(loss[2]), "Learning_rate": float(learning_rate), "loss_step": step}
 
-    def _loss_one_step_late(self, bt, global_step, learning_rate):
-        """Queue a device -> pinned-host copy of this step's loss behind the step and return the previous step's
-        (two pinned slots, one event each): the host never waits for the step it has just launched.
-        -> (loss[3], the global_step it belongs to, that step's learning rate), or (None, None, None) on the
-        first call."""
+    # ---- the loss, one step late: N_LOSS_SLOTS pinned slots in rotation, one event each
+    N_LOSS_SLOTS = 3          # as many as a batch stream has pinned arenas: (arena, slot) pairs repeat with period 3
+
+    def _loss_begin(self):
+        """The slot this step's loss goes to (the caller queues the device -> pinned-host copy behind the step)."""
         if self._loss_ring is None:
-            self._loss_ring = [[torch.zeros(3).pin_memory(), torch.cuda.Event(), None, None] for _ in range(2)]
-        cur = self._loss_slot
+            self._loss_ring = [[torch.zeros(3).pin_memory(), torch.cuda.Event(), None, None]
+                               for _ in range(self.N_LOSS_SLOTS)]
+        return self._loss_slot
+
+    def _loss_end(self, cur, global_step, learning_rate):
+        """Mark slot ``cur`` as in flight and return the previous step's (loss[3], its global_step, its learning
+        rate) -- or (None, None, None) when nothing is waiting (first call, or drained): the host never waits for
+        the step it has just launched."""
+        n = len(self._loss_ring)
         slot = self._loss_ring[cur]
-        slot[0].copy_(bt.loss, non_blocking=True)
         slot[1].record()
         slot[2], slot[3] = global_step, learning_rate
-        self._loss_slot = 1 - cur
+        self._loss_slot = (cur + 1) % n
         self._loss_unread = True
-        prev = self._loss_ring[1 - cur]
+        prev = self._loss_ring[(cur - 1) % n]
         if prev[2] is None:
             return None, None, None
         prev[1].synchronize()
-        return prev[0].numpy().copy(), prev[2], prev[3]
+        out = (prev[0].numpy().copy(), prev[2], prev[3])
+        prev[2] = None
+        return out
+
+    def _latest_slot(self):
+        return self._loss_ring[(self._loss_slot - 1) % len(self._loss_ring)]
 
     def drain_loss(self):
         """(loss, summary) of the most recent step when train() has not handed it over yet (``async_loss``), else
         None; waits for that step.  The trainer calls it before it averages, evaluates, saves or ends an epoch."""
         if self._loss_ring is None or not self._loss_unread:
             return None
-        host, ev, step, lr = self._loss_ring[1 - self._loss_slot]
+        slot = self._latest_slot()
+        host, ev, step, lr = slot
         ev.synchronize()
         self._loss_unread = False
-        # the next train() call must not hand this one over again
-        self._loss_ring[1 - self._loss_slot][2] = None
+        slot[2] = None                         # the next train() call must not hand this one over again
         self.loss_step = step
         loss = host.numpy().copy()
         return float(loss[0]), self._summary(loss, lr, step)
@@ -382,7 +432,7 @@ class base_model(object):
         """The loss of the most recent step (waits for it)."""
         if self._loss_ring is None:
             return None
-        host, ev = self._loss_ring[1 - self._loss_slot][:2]
+        host, ev = self._latest_slot()[:2]
         ev.synchronize()
         return float(host[0])
 

@@ -440,6 +440,48 @@ def test_native_feed_equals_python_feed(hip_lib, tmp_path):
     assert model_a.recall_at(model_a.sess, records[:B], 20) == model_b.recall_at(model_b.sess, packed, 20)
 
 
+@pytest.mark.parametrize("async_loss", [False, True])
+def test_feed_and_loss_copies_inside_the_graph(hip_lib, tmp_path, async_loss):
+    """A PackedBatch step is ONE graph launch: the host -> device copy of the pinned feed arena is the graph's first
+    node (one graph per arena of the stream's pool of three), the loss's device -> host copy its last under
+    async_loss.  12 steps over 4 distinct batches (every arena and every loss slot replayed several times, with new
+    contents each time) against a model fed Python lists with the copies outside the graph: the same loss at every
+    step -- each exactly once under async_loss -- and the same parameters afterwards."""
+    from mtamrecommender_amd.DataHandle.native_input import BatchPacker, NativeDataInput, RecordSet
+    B, L, steps = 16, 20, 12
+    model_a, FLAGS, records = build(tmp_path, 4 * B, L, 1, 1)
+    model_b, _, _ = build(tmp_path, 4 * B, L, 1, 1)
+    rs = RecordSet.from_records(records)
+    packer = BatchPacker(model_b.path, model_b.embedding)
+    model_b.async_loss = async_loss
+    want, got, done = [], {}, 0
+    while done < steps:
+        for i, packed in NativeDataInput(rs, B, packer, consumer="t"):
+            assert model_b._feed_in_graph(packed) and not model_a._feed_in_graph(records[:B])
+            want.append(model_a.train(model_a.sess, records[(i - 1) * B:i * B], 1e-3 * (1 + done % 3), global_step=done)[0])
+            loss, summary = model_b.train(model_b.sess, packed, 1e-3 * (1 + done % 3), global_step=done)
+            if summary["loss_step"] is not None:
+                assert summary["loss_step"] not in got
+                got[summary["loss_step"]] = (loss, summary["Learning_rate"])
+            done += 1
+            if done == steps:
+                break
+    last = model_b.drain_loss()
+    if async_loss:
+        got[last[1]["loss_step"]] = (last[0], last[1]["Learning_rate"])
+    else:
+        assert last is None
+    assert sorted(got) == list(range(steps))
+    for s_ in range(steps):
+        assert abs(got[s_][0] - want[s_]) <= 2e-5 * abs(want[s_]), (s_, got[s_], want[s_])
+        assert abs(got[s_][1] - 1e-3 * (1 + s_ % 3)) < 1e-12            # the learning rate travelled with its step
+    keys = [k for k in model_b._graphs if k[0] == "train_feed" and k[-1] != "warm"]
+    assert len(keys) == 3 and len({k[3] for k in keys}) == 3            # one captured graph per pinned arena
+    va, vb = model_a.get_variables(), model_b.get_variables()
+    for k in va:
+        assert np.abs(va[k] - vb[k]).max() <= 2e-4 * max(1.0, np.abs(va[k]).max()), k
+
+
 @pytest.mark.parametrize("native", [True, False])
 def test_trainer_loop_runs_on_both_feeds(hip_lib, tmp_path, native):
     from mtamrecommender_amd.data.synthetic import SyntheticCatalog, make_records
