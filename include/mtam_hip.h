@@ -267,6 +267,26 @@ int mtam_tagru_bwd(const float *d_short, const float *d_hs, const float *x, cons
                    const float *tvec, const float *save, int B, int L,
                    float *d_xproj, float *rh, float *d_xt, float *d_tvec_partial,
                    void *stream);
+/* The same two launches with the decoder's K/V work riding along as EXTRA workgroups (blockIdx >= B), on the CUs the
+ * recurrence leaves idle (one sample per workgroup keeps B = 128 of the 256 CUs busy for ~46 us; a GRU workgroup holds
+ * or reserves enough LDS that nothing else fits on its CU, so the extra workgroups can only land on the idle ones):
+ *   mtam_tagru_fwd_kv:  also kv_out [B*L, n_kv] = relu(x . Wkv + bkv)   (Model/Modules/time_aware_attention.py:251-253;
+ *                       x is the same [B*L, 128] the recurrence reads), from the bf16 operand images of Wkv
+ *                       (the layout of mtam_seq_chain_fwd's w_images); n_kv a multiple of 32.  The fused lookups +
+ *                       projections launch is then called with n_kv = 0.
+ *   mtam_tagru_bwd_dkv: also d_x [B*L, 128] += d_kv [B*L, 256] . Wkv^T (the K/V projection's gradient towards x), from
+ *                       the images of Wkv's transpose (mtam_seq_chain_bwd's w_images_r layout); n_kv = 256 (one decoder
+ *                       block).  mtam_seq_chain_bwd is then called with n_kv = 0.
+ * wkv_images / d_kv == NULL: exactly mtam_tagru_fwd / mtam_tagru_bwd. */
+int mtam_tagru_fwd_kv(const float *xproj, const float *x, const float *timelast, const int32_t *seq_len,
+                      const float *wh_g, const float *wh_c, const float *tvec, int B, int L, float *hs,
+                      float *short_out, float *save, const uint16_t *wkv_images, const float *bkv, int n_kv,
+                      float *kv_out, void *stream);
+int mtam_tagru_bwd_dkv(const float *d_short, const float *d_hs, const float *x, const float *timelast,
+                       const int32_t *seq_len, const float *wh_g, const float *wh_c, const float *tvec,
+                       const float *save, int B, int L, float *d_xproj, float *rh, float *d_xt,
+                       float *d_tvec_partial, const float *d_kv, int n_kv, const uint16_t *wkv_images_t, float *d_x,
+                       void *stream);
 
 /* The T-SeqRec cell (TimeAwareGRUCell_sigmoid, Model/Modules/time_aware_rnn.py:19-131, used by
  * MTAM_with_T_SeqRec, Model/MTAMRec_model.py:275-306):
@@ -473,14 +493,15 @@ int mtam_seq_chain_fwd(const float *ic, const float *W4, const float *pos, int R
                        float *kv, float *xproj, const uint16_t *w_images, void *stream);
 /* w_images (both chain entry points): NULL = the three products on v_mfma_f32_32x32x2_f32.  Otherwise the bf16
  * operand images of W4, Wkv and Wx -- one buffer of mtam_seq_chain_images_elems(n_kv, n_x) bf16 values,
- * [W4 | Wkv | Wx] (mtam_seq_chain_image_offset(which, n_kv) = where matrix `which` = 0, 1, 2 starts), each matrix as
+ * [W4 | Wx | Wkv] (mtam_seq_chain_image_offset(which, n_x) = where matrix `which` = 0 (W4), 1 (Wkv), 2 (Wx) starts;
+ * Wkv last, so a launch with n_kv = 0 reads the same buffer), each matrix as
  * three images (W = W1 + W2 + W3 exactly, bf16 each; image t at t K N) in the order [K / 8][N][8] -- and every
  * product runs as six v_mfma_f32_32x32x16_bf16 terms with fp32 accumulation: fp32-equivalent (the dropped terms
  * are <= 2^-23 |a b|), 448 fp32 matrix instructions of 64 cycles per wave become 336 of 32.  The images are
  * written by the optimizer launch that updates the weights (mtam_adam_images) -- no per-step prepare launch --
  * or, whenever the weights change any other way, by mtam_split_weight_images (one launch per matrix). */
 size_t mtam_seq_chain_images_elems(int n_kv, int n_x);
-size_t mtam_seq_chain_image_offset(int which, int n_kv);
+size_t mtam_seq_chain_image_offset(int which, int n_x);
 int mtam_split_weight_images(const float *W, int K, int N, uint16_t *images, void *stream);
 /* The backward's sequence-side chain in one launch (the mirror of mtam_seq_chain_fwd; replaces the dual-source
  * mtam_gemm_f32_dual(ACCUM2_MASK) and the d[item | category] GEMM; tf.gradients of
@@ -493,7 +514,7 @@ int mtam_split_weight_images(const float *W, int K, int N, uint16_t *images, voi
  * wider models keep the two GEMM launches).  A workgroup owns a 32-row stripe; d_z
  * stays on the CU between the two products; split-bf16 products (fp32-equivalent).  w_images_r: the bf16 images of
  * the three matrices' TRANSPOSES (the B operands of products with W^T), one buffer laid out like w_images
- * ([W4 | Wkv | Wx], the same offsets): matrix W [K, N] as three terms (term t at t K N), element W[k][n] at
+ * ([W4 | Wx | Wkv], the same offsets): matrix W [K, N] as three terms (term t at t K N), element W[k][n] at
  * ((n >> 3) K + k) 8 + (n & 7), N a multiple of 8.  Written by mtam_adam_images (images_r) or mtam_split_weight_rows. */
 int mtam_split_weight_rows(const float *W, int K, int N, uint16_t *images_r, void *stream);
 int mtam_seq_chain_bwd_max_k(void); /* largest n_x + n_kv the staged stripe holds (640: one decoder block) */

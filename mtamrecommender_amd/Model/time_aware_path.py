@@ -353,9 +353,31 @@ class TimeAwarePath(object):
         which = {"dense4emb/w": 0, "kv/w": 1, "gru/wx": 2}
         for name in names:
             K, N = segs[name].shape
-            o = ops.seq_chain_image_offset(which[name], n_kv)
+            o = ops.seq_chain_image_offset(which[name], n_x)
             self._wimg_parts.append((name, segs[name].offset, K, N, self.wimg[o:], self.wimg_r[o:]))
         self.wimg_descs = ops.weight_image_descs([part[1:] for part in self._wimg_parts])
+
+    def _wimg_of(self, name):
+        """(operand images, images of the transpose) of one weight matrix."""
+        for part in self._wimg_parts:
+            if part[0] == name:
+                return part[4], part[5]
+        raise KeyError(name)
+
+    def _stripe_bwd_on(self, bt):
+        """The backward's sequence-side chain as one stripe kernel (csrc/seq_chain.hip): needs the transposes' images and
+        n_x + n_kv within the staged stripe; MTAM_SEQ_CHAIN_BWD=0 / MTAM_FUSED_SCATTER=1 keep the GEMM launches."""
+        kv_src = self.cfg["attention"] and self.cfg["keys"] == "x"
+        return (self.wimg_r is not None and os.environ.get("MTAM_FUSED_SCATTER", "0") != "1"
+                and (self.wimg_n_kv > 0) == bool(kv_src)
+                and bt.xw * D + self.wimg_n_kv <= ops.seq_chain_bwd_max_k()
+                and os.environ.get("MTAM_SEQ_CHAIN_BWD", "1") != "0")
+
+    def _dkv_role_on(self, bt):
+        """d_x += d_kv . Wkv^T as extra workgroups of the GRU's backward launch (csrc/tagru.hip: dkv_role; one decoder
+        block, keys = x, the stripe kernel behind it); MTAM_KV_ROLES=0 leaves the term in the stripe kernel."""
+        return (self._stripe_bwd_on(bt) and self.wimg_n_kv == 2 * D and self.cfg["gru"] in ("time", "plain")
+                and os.environ.get("MTAM_KV_ROLES", "1") != "0")
 
     def refresh_weight_images(self):
         for name, _, _, _, img, img_r in self._wimg_parts:
@@ -421,6 +443,11 @@ class TimeAwarePath(object):
         clear = (self.zero_prefix, bt.d_clear if cfg["keys"] == "gru" else bt.d_pred.view(-1)) if training else ()
         keys = bt.hs if cfg["keys"] == "gru" else bt.x        # user_history: what the decoder attends over
         kv_from_x = cfg["attention"] and cfg["keys"] == "x"    # keys/values of every block (before the GRU)
+        # ... computed by extra workgroups of the GRU launch, on the CUs the recurrence leaves idle, instead of by the
+        # fused projection kernel (csrc/tagru.hip: kv_role; MTAM_KV_ROLES=0 keeps it in the projection kernel)
+        kv_role = (kv_from_x and self.wimg is not None and cfg["gru"] in ("time", "plain")
+                   and os.environ.get("MTAM_KV_ROLES", "1") != "0")
+        kv_in_chain = kv_from_x and not kv_role
         # dense4emb, the K/V projection and the GRU's input projection in ONE launch (a 32-row stripe of x
         # stays on its CU; 16-byte stores): 25.5 us against 35.4 us as three GEMMs at 6,400 rows.
         # MTAM_SEQ_CHAIN=0 keeps the three GEMMs.
@@ -433,9 +460,9 @@ class TimeAwarePath(object):
             ops.seq_chain_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
                                      fd["category_list"], fd["position_list"], fd["user_id"], B, L, 1,
                                      self.seg("dense4emb/w"),
-                                     self.seg("kv/w") if kv_from_x else None, self.seg("kv/b") if kv_from_x else None,
+                                     self.seg("kv/w") if kv_in_chain else None, self.seg("kv/b") if kv_in_chain else None,
                                      self.seg("gru/wx"), self.seg("gru/bx"), bt.ic if training else None, bt.user,
-                                     bt.l2_fused, bt.zr, bt.x, bt.kv if kv_from_x else None, bt.xproj, clear=clear,
+                                     bt.l2_fused, bt.zr, bt.x, bt.kv if kv_in_chain else None, bt.xproj, clear=clear,
                                      w_images=self.wimg)
             bt.l2_live = bt.l2_fused          # 4 sums per 32-row stripe: what the loss reduction has to read
         else:
@@ -447,12 +474,12 @@ class TimeAwarePath(object):
             pass
         elif chain:
             ops.seq_chain_fwd(bt.ic, self.seg("dense4emb/w"), bt.pos, R,
-                              self.seg("kv/w") if kv_from_x else None, self.seg("kv/b") if kv_from_x else None,
-                              self.seg("gru/wx"), self.seg("gru/bx"), bt.zr, bt.x, bt.kv if kv_from_x else None,
+                              self.seg("kv/w") if kv_in_chain else None, self.seg("kv/b") if kv_in_chain else None,
+                              self.seg("gru/wx"), self.seg("gru/bx"), bt.zr, bt.x, bt.kv if kv_in_chain else None,
                               bt.xproj, w_images=self.wimg)
         else:
             ops.gemm(bt.ic, self.seg("dense4emb/w"), bt.x, epilogue=ops.EPI_RELU_ADD, aux_in=bt.pos, aux_out=bt.zr)
-            if kv_from_x:
+            if kv_in_chain:
                 ops.gemm(bt.x, self.seg("kv/w"), bt.kv, epilogue=ops.EPI_BIAS_RELU, bias=self.seg("kv/b"))
         if cfg["gru"] == "seqrec":
             # TimeAwareGRUCell_sigmoid: gate and candidate input halves (columns 0 .. 3 D) and the two
@@ -471,8 +498,10 @@ class TimeAwarePath(object):
             if not chain:
                 ops.gemm(bt.x, self.seg("gru/wx"), bt.xproj, epilogue=ops.EPI_BIAS, bias=self.seg("gru/bx"))
             tvec = self.seg("gru/tvec") if cfg["gru"] == "time" else None
+            kv_job = (self._wimg_of("kv/w")[0], self.seg("kv/b"), bt.kv) if kv_role else None
             ops.tagru_fwd(bt.xproj, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
-                          self.seg("gru/wh_c"), tvec, B, L, bt.hs, bt.short, bt.gru_save if training else None)
+                          self.seg("gru/wh_c"), tvec, B, L, bt.hs, bt.short, bt.gru_save if training else None,
+                          kv=kv_job)
         if cfg["short_ln"]:
             sl = self.seg("short/ln")
             ops.layer_norm_fwd(bt.short, sl[0], sl[1], 1e-12, B, bt.short_n, bt.short_ln_save if training else None)
@@ -582,9 +611,13 @@ class TimeAwarePath(object):
             jobs.append((bt.d_tvec4_rows, R, 4 * D, 4 * D, gseg("gru/tsr_tvec").view(-1)))
         else:
             tvec = self.seg("gru/tvec") if cfg["gru"] == "time" else None
+            # d_x += d_kv . Wkv^T (the K/V projection's gradient towards x) rides with the GRU's backward launch as
+            # extra workgroups; the stripe kernel below then runs without its d_kv source
+            dkv_role = self._dkv_role_on(bt)
             ops.tagru_bwd(d_short, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
                           self.seg("gru/wh_c"), tvec, bt.gru_save, B, L, bt.d_xproj, bt.rh, bt.d_xt,
-                          bt.d_tvec_partial, d_hs=bt.d_hs if cfg["keys"] == "gru" else None)
+                          bt.d_tvec_partial, d_hs=bt.d_hs if cfg["keys"] == "gru" else None,
+                          dkv=(bt.d_kv, self._wimg_of("kv/w")[1], bt.d_x) if dkv_role else None)
         problems = [prob(bt.x, D, bt.d_xproj, xw, "gru/wx", D, xw, R, sr),
                     prob(bt.gru_save.view(-1)[4 * D:], ns, bt.d_xproj, xw, "gru/wh_g", D, 2 * D, R, sr),
                     prob(bt.rh, D, bt.d_xproj.view(-1)[2 * D:], xw, "gru/wh_c", D, D, R, sr)] + problems
@@ -604,11 +637,10 @@ class TimeAwarePath(object):
         kv_src = cfg["attention"] and cfg["keys"] == "x"
         # the whole chain in ONE stripe kernel (d_z never leaves the CU between the two products; split-bf16 products
         # on the images of the weights' transposes): MTAM_SEQ_CHAIN_BWD=0 keeps the two GEMM launches
-        stripe = (self.wimg_r is not None and not fused_scatter and (self.wimg_n_kv > 0) == bool(kv_src)
-                  and bt.xw * D + self.wimg_n_kv <= ops.seq_chain_bwd_max_k()
-                  and os.environ.get("MTAM_SEQ_CHAIN_BWD", "1") != "0")
+        stripe = self._stripe_bwd_on(bt)
         if stripe:
-            ops.seq_chain_bwd(bt.d_xproj, bt.d_kv if kv_src else None, bt.d_xt, bt.zr, R, bt.d_x, bt.d_z, bt.d_ic,
+            in_stripe = kv_src and not self._dkv_role_on(bt)
+            ops.seq_chain_bwd(bt.d_xproj, bt.d_kv if in_stripe else None, bt.d_xt, bt.zr, R, bt.d_x, bt.d_z, bt.d_ic,
                               self.wimg_r)
         elif kv_src:
             ops.gemm_dual(bt.d_xproj, self.seg("gru/wx"), bt.d_kv, self.seg("kv/w"), bt.d_x, trans_b=True,

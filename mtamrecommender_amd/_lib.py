@@ -55,6 +55,8 @@ SIGNATURES = {
     "mtam_seq_chain_bwd": (c_int, [P, c_int, P, c_int, P, P, c_int, P, P, P, P, P]),
     "mtam_tagru_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "mtam_tagru_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
+    "mtam_tagru_fwd_kv": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, c_int, P, P]),
+    "mtam_tagru_bwd_dkv": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, c_int, P, P, P]),
     "mtam_tagru_seqrec_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),
     "mtam_tagru_seqrec_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
     "mtam_tsr_time_inputs_fwd": (c_int, [P, P, P, c_int, P, P]),

@@ -16,6 +16,7 @@
 // registers, a whole column block ahead of their use.  Two independent accumulator chains per tile.
 #include "common.h"
 #include "split_bf16.h"
+#include "stripe_tile.h"
 
 namespace {
 using split_bf16::bf16x4;
@@ -23,28 +24,13 @@ using split_bf16::bf16x8;
 using split_bf16::Tri;
 
 constexpr int D = MTAM_D;
-constexpr int ROWS = 32;              // stripe height
+using stripe::f32x16;
+using stripe::f32x4;
+using stripe::ROWS;
+using stripe::store_tile;
+using stripe::T_PITCH;
 constexpr int A_PITCH = 2 * D + 2;    // staged [item | category] row: [128][gap][128][gap]
 constexpr int X_PITCH = D + 2;        // staged x row: [64][gap][64][gap]
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int T_PITCH = 36;           // transposition scratch: 32 rows x (32 + 4) floats per wave
-// A 32 x 32 accumulator tile has its column on the lane (16 four-byte stores of 128-byte segments per lane):
-// through a wave-private LDS scratch it leaves as 4 sixteen-byte stores per lane (8 rows x 128 B each).
-__device__ __forceinline__ void store_tile(float *scratch, const f32x16 &v, float *out, long row0, int R, int ld,
-                                           int col0, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) scratch[((q & 3) + 8 * (q >> 2) + 4 * h) * T_PITCH + r] = v[q];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = i * 64 + lane, row = idx >> 3, c4 = idx & 7;
-    const f32x4 t = *reinterpret_cast<const f32x4 *>(scratch + row * T_PITCH + 4 * c4);
-    if (row0 + row < R) *reinterpret_cast<f32x4 *>(out + (row0 + row) * ld + col0 + 4 * c4) = t;
-  }
-}
 
 struct ChainArgs {
   const float *ic, *W4, *pos;
@@ -631,12 +617,13 @@ __global__ __launch_bounds__(256) void split_weight_images_kernel(const float *_
   if (i < (size_t)K * N) split_bf16::wimg_store(img, K, N, (int)(i / N), (int)(i % N), W[i]);
 }
 
-// the one buffer the entry points take: [W4 images | Wkv images | Wx images], each 3 K N bf16
+// the one buffer the entry points take: [W4 images | Wx images | Wkv images], each 3 K N bf16 (Wkv last: where
+// W4's and Wx's images lie does not depend on whether the launch computes the K/V projection)
 void set_images(ChainArgs &a, const uint16_t *w_images) {
   if (!w_images) return;
   a.img4 = w_images;
-  a.imgkv = a.img4 + split_bf16::wimg_elems(2 * D, D);
-  a.imgx = a.imgkv + split_bf16::wimg_elems(D, a.n_kv);
+  a.imgx = a.img4 + split_bf16::wimg_elems(2 * D, D);
+  a.imgkv = a.imgx + split_bf16::wimg_elems(D, a.n_x);
 }
 
 }  // namespace
@@ -645,8 +632,8 @@ extern "C" size_t mtam_seq_chain_images_elems(int n_kv, int n_x) {
   return split_bf16::wimg_elems(2 * D, D) + split_bf16::wimg_elems(D, n_kv) + split_bf16::wimg_elems(D, n_x);
 }
 
-extern "C" size_t mtam_seq_chain_image_offset(int which, int n_kv) {
-  return which == 0 ? 0 : split_bf16::wimg_elems(2 * D, D) + (which == 1 ? 0 : split_bf16::wimg_elems(D, n_kv));
+extern "C" size_t mtam_seq_chain_image_offset(int which, int n_x) {
+  return which == 0 ? 0 : split_bf16::wimg_elems(2 * D, D) + (which == 2 ? 0 : split_bf16::wimg_elems(D, n_x));
 }
 
 extern "C" int mtam_split_weight_images(const float *W, int K, int N, uint16_t *images, void *stream) {
@@ -686,8 +673,8 @@ extern "C" int mtam_seq_chain_bwd(const float *d_xproj, int n_x, const float *d_
   a.d_xproj = d_xproj; a.d_kv = d_kv; a.d_xt = d_xt; a.zr = zr; a.R = R; a.n_x = n_x; a.n_kv = n_kv;
   a.d_x = d_x; a.d_z = d_z; a.d_ic = d_ic;
   a.rimg4 = w_images_r;
-  a.rimgkv = a.rimg4 + split_bf16::wimg_elems(2 * D, D);
-  a.rimgx = a.rimgkv + split_bf16::wimg_elems(D, n_kv);
+  a.rimgx = a.rimg4 + split_bf16::wimg_elems(2 * D, D);
+  a.rimgkv = a.rimgx + split_bf16::wimg_elems(D, n_x);
   static bool attr_set = false;
   if (!attr_set) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(seq_chain_bwd_kernel),

@@ -26,6 +26,8 @@
 // (4 barriers / 8 waves: 1.0; 2 barriers / 8 waves: 0.95; 16 waves with one unit per octet: 1.0 -- four waves
 // per SIMD starve the youngest; 8 waves, two units per octet, all per-step traffic staged in LDS: 0.8).
 #include "common.h"
+#include "split_bf16.h"
+#include "stripe_tile.h"
 
 // In-kernel stamps for tools/gru_lab.hip (a diagnostic build, -DMTAM_GRU_STAMPS): cycles per segment of a
 // step, summed per wave of workgroup 0 and written to a buffer of their own.  The product build has none.
@@ -171,7 +173,77 @@ struct FwdArgs {
   const float *wh_g, *wh_c, *tvec;
   int B, L, ldx;
   float *hs, *short_out, *save;
+  // K/V role (workgroups blockIdx >= B of the same launch, on the CUs the recurrence leaves idle):
+  // kv_out [B L, kv_n] = relu(x . Wkv + kv_bias) from the bf16 operand images of Wkv (kv_img); NULL = no role
+  const uint16_t *kv_img;
+  const float *kv_bias;
+  float *kv_out;
+  int kv_n;
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Work co-scheduled with the recurrence.  A GRU launch keeps 128 of the 256 CUs busy for ~46 us (one sample per
+// workgroup, 150 KB of LDS each -- or, in the backward, a dynamic LDS reservation of the same effect: nothing else
+// fits beside a GRU workgroup on its CU).  The decoder's K/V work does not depend on the recurrence, so it rides in
+// the SAME launches as extra workgroups (blockIdx >= B), which the dispatcher can only place on the idle CUs:
+//   forward   kv = relu(x Wkv + bkv)            (Model/Modules/time_aware_attention.py:251-253) leaves the fused
+//             lookups + projections kernel: 21.1 -> 16.6 us
+//   backward  d_x += d_kv Wkv^T                 (its gradient towards x) leaves the backward stripe kernel: 20.5 -> 16.8 us
+// As launches of their own these products take 7.8 and 8.1 us; here they end long before the recurrence does.
+// Both are split-bf16 products on the weight images the optimizer launch writes (csrc/seq_chain.hip).
+using split_bf16::bf16x4;
+using split_bf16::bf16x8;
+using split_bf16::Tri;
+using stripe::f32x16;
+using stripe::f32x4;
+
+constexpr int KV_ROLE_LDS = stripe::ROWS * stripe::X_PITCH * 4 + 8 * stripe::ROWS * stripe::T_PITCH * 4;      // 53,760 B
+
+// 512 threads, one 32-row stripe of x: wave w owns column blocks w, w + 8, ... of the kv_n / 32
+__device__ __forceinline__ void kv_role(const FwdArgs &p, int stripe_id, float *lds) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const long row0 = (long)stripe_id * stripe::ROWS;
+  const int R = p.B * p.L, n_kv = p.kv_n;
+  constexpr int XP = stripe::X_PITCH;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = i * 512 + tid, row = id >> 5, c4 = id & 31;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(p.x + min(row0 + row, (long)R - 1) * D + c4 * 4);
+    *reinterpret_cast<f32x4 *>(lds + row * XP + c4 * 4) = v;
+  }
+  __syncthreads();
+  Tri af[8];
+  {
+    const float *a = lds + r * XP + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(a + 16 * s), hi = *reinterpret_cast<const f32x4 *>(a + 16 * s + 4);
+      const float x8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      af[s] = split_bf16::split8(x8);
+    }
+  }
+  float *scratch = lds + stripe::ROWS * XP + w * (stripe::ROWS * stripe::T_PITCH);
+  const size_t term = (size_t)D * n_kv;
+  for (int j = w; j < n_kv / 32; j += 8) {
+    const int col = 32 * j + r;
+    const uint16_t *base = p.kv_img + ((size_t)h * n_kv + col) * 8;
+    Tri bw[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        bw[s].t[t] = *reinterpret_cast<const bf16x8 *>(base + t * term + (size_t)s * (2 * n_kv * 8));
+    const float bias = p.kv_bias[col];
+    f32x16 a0 = {0.f}, a1 = {0.f};
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) split_bf16::mfma6x2(af[s], bw[s], a0, af[s + 1], bw[s + 1], a1);
+    const f32x16 acc = a0 + a1;
+    f32x16 o;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) o[q] = fmaxf(acc[q] + bias, 0.f);
+    stripe::store_tile(scratch, o, p.kv_out, row0, R, n_kv, 32 * j, lane);
+  }
+}
 
 // ---- forward ----------------------------------------------------------------------------------------------
 //  * 8 waves (512 threads, two per SIMD); octet q2 owns hidden units 2 q2 and 2 q2 + 1 entirely: their r, u and
@@ -197,6 +269,11 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
   __shared__ __attribute__((aligned(16))) float rh_s[D + 8];
   __shared__ float carry_s[D];             // the last state of the previous chunk (h_prev of a chunk's first step)
 
+  if ((int)blockIdx.x >= p.B) {             // the K/V role: not a sample but a 32-row stripe of x (see kv_role)
+    static_assert(sizeof(stage) >= KV_ROLE_LDS, "the K/V role's LDS lives in the staging buffer");
+    kv_role(p, blockIdx.x - p.B, stage);
+    return;
+  }
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int kp = lane & 7, q2 = tid >> 3;  // octet q2 (0..63) owns hidden units 2 q2 and 2 q2 + 1
@@ -410,7 +487,93 @@ struct BwdArgs {
   const float *wh_g, *wh_c, *tvec, *save;
   int B, L, ldx;
   float *d_xproj, *rh, *d_xt, *d_tvec_partial;
+  // d_kv role (workgroups blockIdx >= B): d_x [B L, D] += d_kv [B L, 256] . Wkv^T from the images of Wkv's
+  // transpose (dkv_img); NULL = no role
+  const float *d_kv;
+  const uint16_t *dkv_img;
+  float *d_x;
 };
+
+constexpr int DKV_N = 2 * D;                                    // the role is built for one decoder block: d_kv [R, 256]
+constexpr int DKV_PITCH = DKV_N * 2 + 16;                       // bytes per staged row of one image
+constexpr int DKV_IMG = stripe::ROWS * DKV_PITCH;
+constexpr int DKV_ROLE_LDS = 3 * DKV_IMG + 8 * stripe::ROWS * stripe::T_PITCH * 4;        // 87,552 B (dynamic)
+
+// 512 threads, one 32-row stripe: wave w owns output column block w & 3 over k-steps 8 (w >> 2) .. + 8 of the 16;
+// the two halves of a column block meet in LDS and waves 0..3 add them onto d_x (16-byte read-modify-write)
+__device__ __forceinline__ void dkv_role(const BwdArgs &p, int stripe_id, unsigned char *lds) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const long row0 = (long)stripe_id * stripe::ROWS;
+  const int R = p.B * p.L;
+  const int cb = w & 3, kh = w >> 2;
+  // B fragments: rows n = 32 cb + r of Wkv, columns k = 128 kh + 16 s + 8 h .. + 8 -- pieces of the transpose's image
+  Tri bw[8];
+  {
+    const uint16_t *base = p.dkv_img + ((size_t)(16 * kh + h) * D + 32 * cb + r) * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        bw[s].t[t] = *reinterpret_cast<const bf16x8 *>(base + (size_t)t * (D * DKV_N) + (size_t)s * (2 * D * 8));
+  }
+  {
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = i * 512 + tid, row = id >> 6, c4 = id & 63;
+      v[i] = *reinterpret_cast<const f32x4 *>(p.d_kv + min(row0 + row, (long)R - 1) * DKV_N + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = i * 512 + tid, row = id >> 6, c4 = id & 63;
+      const float x4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+      bf16x4 q[3];
+      split_bf16::split4(x4, q);
+      unsigned char *dst = lds + row * DKV_PITCH + c4 * 8;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4 *>(dst + t * DKV_IMG) = q[t];
+    }
+  }
+  __syncthreads();
+  f32x16 a0 = {0.f}, a1 = {0.f};
+  {
+    const unsigned char *ab = lds + r * DKV_PITCH + kh * (8 * 32) + h * 16;
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) {
+      Tri fa, fb;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        fa.t[t] = *reinterpret_cast<const bf16x8 *>(ab + t * DKV_IMG + s * 32);
+        fb.t[t] = *reinterpret_cast<const bf16x8 *>(ab + t * DKV_IMG + (s + 1) * 32);
+      }
+      split_bf16::mfma6x2(fa, bw[s], a0, fb, bw[s + 1], a1);
+    }
+  }
+  float *scratch = reinterpret_cast<float *>(lds + 3 * DKV_IMG) + w * (stripe::ROWS * stripe::T_PITCH);
+  {
+    const f32x16 acc = a0 + a1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) scratch[((q & 3) + 8 * (q >> 2) + 4 * h) * stripe::T_PITCH + r] = acc[q];
+  }
+  __syncthreads();
+  if (w < 4) {
+    const float *mine = scratch, *other = scratch + 4 * (stripe::ROWS * stripe::T_PITCH);
+    const int gn = 32 * cb + 4 * (lane & 7);
+    f32x4 t[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lr = 8 * i + (lane >> 3);
+      t[i] = *reinterpret_cast<const f32x4 *>(mine + lr * stripe::T_PITCH + 4 * (lane & 7)) +
+             *reinterpret_cast<const f32x4 *>(other + lr * stripe::T_PITCH + 4 * (lane & 7));
+      c[i] = *reinterpret_cast<const f32x4 *>(p.d_x + min(row0 + lr, (long)R - 1) * D + gn);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lr = 8 * i + (lane >> 3);
+      if (row0 + lr < R) *reinterpret_cast<f32x4 *>(p.d_x + (row0 + lr) * D + gn) = c[i] + t[i];
+    }
+  }
+}
 
 // Backward through time, cut by output column (the 2-barrier form; an LDS-staged variant like the forward's
 // measured 52.0 us against this kernel's 48.3: profiles/r02_tagru_v4b_batched_staging.hip.txt): output k of both transposed products (d(r*h) = dcpre . Wc_h^T over
@@ -420,6 +583,13 @@ struct BwdArgs {
 __global__ __launch_bounds__(512) void tagru_bwd_kernel(BwdArgs p) {
   __shared__ __attribute__((aligned(16))) float dc_s[D + 8];
   __shared__ __attribute__((aligned(16))) float dg_s[2 * D + 16];
+  // dynamic: DKV_ROLE_LDS bytes when the d_kv role rides along (its staging; for the recurrence's own workgroups a
+  // reservation that keeps any second workgroup off their CU), else nothing
+  extern __shared__ __attribute__((aligned(16))) unsigned char role_lds[];
+  if ((int)blockIdx.x >= p.B) {
+    dkv_role(p, blockIdx.x - p.B, role_lds);
+    return;
+  }
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -592,14 +762,28 @@ extern "C" int mtam_tagru_fwd(const float *xproj, const float *x, const float *t
                               const int32_t *seq_len, const float *wh_g, const float *wh_c,
                               const float *tvec, int B, int L, float *hs, float *short_out,
                               float *save, void *stream) {
+  return mtam_tagru_fwd_kv(xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save, nullptr, nullptr,
+                           0, nullptr, stream);
+}
+
+extern "C" int mtam_tagru_fwd_kv(const float *xproj, const float *x, const float *timelast,
+                                 const int32_t *seq_len, const float *wh_g, const float *wh_c,
+                                 const float *tvec, int B, int L, float *hs, float *short_out,
+                                 float *save, const uint16_t *wkv_images, const float *bkv, int n_kv, float *kv_out,
+                                 void *stream) {
   MTAM_CHECK_ARG(B > 0 && L > 0, "tagru_fwd: B and L must be positive");
+  MTAM_CHECK_ARG(!wkv_images || (bkv && kv_out && n_kv > 0 && n_kv % 32 == 0 && mtam_aligned16(wkv_images) &&
+                                 mtam_aligned16(kv_out) && mtam_aligned16(x)),
+                 "tagru_fwd_kv: the K/V role needs bkv, kv_out and n_kv a multiple of 32 (16-byte aligned operands)");
   MTAM_CHECK_ARG(xproj && x && timelast && seq_len && wh_g && wh_c && hs && short_out,
                  "tagru_fwd: null argument");        // tvec may be NULL: plain GRUCell
   MTAM_CHECK_ARG(mtam_aligned16(wh_g) && mtam_aligned16(wh_c), "tagru_fwd: weights must be 16-byte aligned");
   MTAM_CHECK_ARG(mtam_aligned16(xproj) && mtam_aligned16(hs) && mtam_aligned16(save),
                  "tagru_fwd: xproj, hs and save must be 16-byte aligned");
-  FwdArgs a{xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, 3 * D, hs, short_out, save};
-  hipLaunchKernelGGL(tagru_fwd_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), a);
+  FwdArgs a{xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, 3 * D, hs, short_out, save, wkv_images, bkv, kv_out,
+            wkv_images ? n_kv : 0};
+  const int stripes = wkv_images ? (B * L + stripe::ROWS - 1) / stripe::ROWS : 0;
+  hipLaunchKernelGGL(tagru_fwd_kernel, dim3(B + stripes), dim3(512), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("tagru_fwd");
   return MTAM_OK;
 }
@@ -608,7 +792,19 @@ extern "C" int mtam_tagru_bwd(const float *d_short, const float *d_hs, const flo
                               const int32_t *seq_len, const float *wh_g, const float *wh_c,
                               const float *tvec, const float *save, int B, int L, float *d_xproj,
                               float *rh, float *d_xt, float *d_tvec_partial, void *stream) {
+  return mtam_tagru_bwd_dkv(d_short, d_hs, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xproj, rh, d_xt,
+                            d_tvec_partial, nullptr, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int mtam_tagru_bwd_dkv(const float *d_short, const float *d_hs, const float *x, const float *timelast,
+                                  const int32_t *seq_len, const float *wh_g, const float *wh_c,
+                                  const float *tvec, const float *save, int B, int L, float *d_xproj,
+                                  float *rh, float *d_xt, float *d_tvec_partial, const float *d_kv, int n_kv,
+                                  const uint16_t *wkv_images_t, float *d_x, void *stream) {
   MTAM_CHECK_ARG(B > 0 && L > 0, "tagru_bwd: B and L must be positive");
+  MTAM_CHECK_ARG(!d_kv || (n_kv == DKV_N && wkv_images_t && d_x && mtam_aligned16(d_kv) && mtam_aligned16(d_x) &&
+                           mtam_aligned16(wkv_images_t)),
+                 "tagru_bwd_dkv: the d_kv role is built for n_kv = %d (one decoder block), 16-byte aligned operands", DKV_N);
   MTAM_CHECK_ARG(d_short && x && timelast && seq_len && wh_g && wh_c && save && d_xproj && rh && d_xt &&
                      d_tvec_partial,
                  "tagru_bwd: null argument");        // tvec (plain GRUCell) and d_hs may be NULL
@@ -616,8 +812,19 @@ extern "C" int mtam_tagru_bwd(const float *d_short, const float *d_hs, const flo
   MTAM_CHECK_ARG(mtam_aligned16(save) && mtam_aligned16(d_xproj) && mtam_aligned16(rh) && mtam_aligned16(d_xt),
                  "tagru_bwd: save, d_xproj, rh and d_xt must be 16-byte aligned");
   BwdArgs a{d_short, d_hs, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, 3 * D, d_xproj, rh, d_xt,
-            d_tvec_partial};
-  hipLaunchKernelGGL(tagru_bwd_kernel, dim3(B), dim3(512), 0, static_cast<hipStream_t>(stream), a);
+            d_tvec_partial, d_kv, wkv_images_t, d_x};
+  const int stripes = d_kv ? (B * L + stripe::ROWS - 1) / stripe::ROWS : 0;
+  if (d_kv) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tagru_bwd_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, DKV_ROLE_LDS);
+      MTAM_CHECK_ARG(e == hipSuccess, "tagru_bwd_dkv: cannot reserve %d bytes of LDS: %s", DKV_ROLE_LDS, hipGetErrorString(e));
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(tagru_bwd_kernel, dim3(B + stripes), dim3(512), d_kv ? DKV_ROLE_LDS : 0,
+                     static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("tagru_bwd");
   return MTAM_OK;
 }

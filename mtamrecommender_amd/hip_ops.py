@@ -179,18 +179,27 @@ def emb_scatter_add_items_range(d_ic, ic, item_ids, seq_len, B, L, reg, g_item, 
     _lib.check(rc, "mtam_emb_scatter_add_bwd_range")
 
 
-def tagru_fwd(xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save):
+def tagru_fwd(xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save, kv=None):
+    """kv = (Wkv operand images, bkv, kv_out [B L, n_kv]): the K/V projection relu(x Wkv + bkv) rides in the same
+    launch as extra workgroups on the CUs the recurrence leaves idle."""
     lib = _lib.load()
-    rc = lib.mtam_tagru_fwd(_p(xproj), _p(x), _p(timelast), _pi(seq_len), _p(wh_g), _p(wh_c), _p(tvec),
-                            B, L, _p(hs), _p(short_out), _p(save), _stream())
+    img, bkv, kv_out = kv if kv is not None else (None, None, None)
+    rc = lib.mtam_tagru_fwd_kv(_p(xproj), _p(x), _p(timelast), _pi(seq_len), _p(wh_g), _p(wh_c), _p(tvec),
+                               B, L, _p(hs), _p(short_out), _p(save), _pb(img) if img is not None else None, _p(bkv),
+                               kv_out.shape[1] if kv_out is not None else 0, _p(kv_out), _stream())
     _lib.check(rc, "mtam_tagru_fwd")
 
 
 def tagru_bwd(d_short, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xproj, rh, d_x,
-              d_tvec_partial, d_hs=None):
+              d_tvec_partial, d_hs=None, dkv=None):
+    """dkv = (d_kv [B L, 256], images of Wkv's transpose, d_x_keys [B L, 128]): d_x_keys += d_kv Wkv^T rides in the
+    same launch as extra workgroups.  (``d_x`` here is the GRU's own time-gate path output, d_xt.)"""
     lib = _lib.load()
-    rc = lib.mtam_tagru_bwd(_p(d_short), _p(d_hs), _p(x), _p(timelast), _pi(seq_len), _p(wh_g), _p(wh_c), _p(tvec),
-                            _p(save), B, L, _p(d_xproj), _p(rh), _p(d_x), _p(d_tvec_partial), _stream())
+    d_kv, img_t, d_xk = dkv if dkv is not None else (None, None, None)
+    rc = lib.mtam_tagru_bwd_dkv(_p(d_short), _p(d_hs), _p(x), _p(timelast), _pi(seq_len), _p(wh_g), _p(wh_c), _p(tvec),
+                                _p(save), B, L, _p(d_xproj), _p(rh), _p(d_x), _p(d_tvec_partial), _p(d_kv),
+                                d_kv.shape[1] if d_kv is not None else 0, _pb(img_t) if img_t is not None else None,
+                                _p(d_xk), _stream())
     _lib.check(rc, "mtam_tagru_bwd")
 
 
@@ -401,8 +410,9 @@ def seq_chain_images_elems(n_kv, n_x):
     return int(_lib.load().mtam_seq_chain_images_elems(int(n_kv), int(n_x)))
 
 
-def seq_chain_image_offset(which, n_kv):
-    return int(_lib.load().mtam_seq_chain_image_offset(int(which), int(n_kv)))
+def seq_chain_image_offset(which, n_x):
+    """First element of matrix ``which`` (0: W4, 1: Wkv, 2: Wx) in the image buffer [W4 | Wx | Wkv]."""
+    return int(_lib.load().mtam_seq_chain_image_offset(int(which), int(n_x)))
 
 
 def split_weight_images(W, images):

@@ -18,7 +18,7 @@ def images(n_kv):
     bufr = torch.zeros_like(buf)
     for which, W in ((0, W4), (1, Wkv if n_kv else None), (2, Wx)):
         if W is not None:
-            o = ops.seq_chain_image_offset(which, n_kv)
+            o = ops.seq_chain_image_offset(which, 384)
             ops.split_weight_images(W, buf[o:]); ops.split_weight_rows(W, bufr[o:])
     return buf, bufr
 ic, user, zr, x, kv, xproj = f(R, 2 * D), f(B, D), f(R, D), f(R, D), f(R, 256), f(R, 384)

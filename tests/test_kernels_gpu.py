@@ -348,6 +348,62 @@ def _gru_device_args(w):
     return Wx, bx, np.ascontiguousarray(Wg[D:]), np.ascontiguousarray(Wc[D:]), tvec
 
 
+@pytest.mark.parametrize("B,L,n_kv", [(3, 5, 256), (128, 50, 256), (16, 50, 512), (7, 9, 32)])
+def test_gru_launches_carry_the_kv_work(ops, B, L, n_kv):
+    """mtam_tagru_fwd_kv / mtam_tagru_bwd_dkv: the decoder's K/V projection relu(x Wkv + bkv) and its gradient
+    towards x (d_x += d_kv Wkv^T) ride in the GRU's own launches as extra workgroups.  The recurrence's outputs are
+    BIT-IDENTICAL to the launches without the riders (the same code runs on the same inputs), the riders' results
+    match float64 to the tolerance of the GEMMs they replace (2e-5) and the split-bf16 GEMM to fp32 rounding."""
+    rng = np.random.default_rng(B * 5 + L + n_kv)
+    w = _gru_weights(rng)
+    R = B * L
+    x = rng.uniform(-0.5, 0.5, (R, D)).astype(np.float32)
+    tl = np.floor(rng.exponential(24.0, R)).astype(np.float32)
+    sl = rng.integers(2, L + 1, size=B).astype(np.int32)
+    Wx, bx, whg, whc, tvec = _gru_device_args(w)
+    xproj = dev((x.astype(np.float64) @ Wx + bx).astype(np.float32))
+    xd, tld, sld, whg, whc, tvec = dev(x), dev(tl), dev(sl), dev(whg), dev(whc), dev(tvec)
+    Wkv = dev((rng.standard_normal((D, n_kv)) * 0.1).astype(np.float32))
+    bkv = dev(rng.standard_normal(n_kv).astype(np.float32))
+    img, img_t = (torch.zeros(3 * D * n_kv, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+    ops.split_weight_images(Wkv, img)
+    ops.split_weight_rows(Wkv, img_t)
+    z = lambda *shape: torch.full(shape, 5.0, device="cuda")
+    plain = [z(R, D), z(B, D), z(R, 5 * D)]
+    ops.tagru_fwd(xproj, xd, tld, sld, whg, whc, tvec, B, L, *plain)
+    ridden, kv = [z(R, D), z(B, D), z(R, 5 * D)], z(R, n_kv)
+    ops.tagru_fwd(xproj, xd, tld, sld, whg, whc, tvec, B, L, *ridden, kv=(img, bkv, kv))
+    for a, b in zip(plain, ridden):
+        assert torch.equal(a, b)
+    ref = np.maximum(x.astype(np.float64) @ Wkv.double().cpu().numpy() + bkv.double().cpu().numpy(), 0.0)
+    assert rel_err(kv.cpu().numpy(), ref) < 2e-5
+    want = z(R, n_kv)
+    ops.gemm(xd, Wkv, want, epilogue=ops.EPI_BIAS_RELU, bias=bkv)
+    assert rel_err(kv.cpu().numpy(), want.cpu().numpy()) < 2e-6
+    pre = x.astype(np.float64) @ Wkv.double().cpu().numpy() + bkv.double().cpu().numpy()
+    clear = np.abs(pre) > 1e-4          # (the relu mask is exact where the pre-activation is not within rounding of zero)
+    assert np.array_equal((kv.cpu().numpy() > 0)[clear], (pre > 0)[clear])
+    if n_kv != 256:
+        with pytest.raises(RuntimeError):           # the backward rider is built for one decoder block
+            ops.tagru_bwd(dev(x[:B]), xd, tld, sld, whg, whc, tvec, plain[2], B, L, z(R, 3 * D), z(R, D), z(R, D),
+                          torch.zeros((B, 8, D), device="cuda"), dkv=(z(R, n_kv), img_t, z(R, D)))
+        return
+    d_short = dev(rng.standard_normal((B, D)).astype(np.float32))
+    d_kv = dev(rng.standard_normal((R, n_kv)).astype(np.float32))
+    d_x0 = rng.standard_normal((R, D)).astype(np.float32)
+    outs_a = [z(R, 3 * D), z(R, D), z(R, D), torch.zeros((B, 8, D), device="cuda")]
+    ops.tagru_bwd(d_short, xd, tld, sld, whg, whc, tvec, plain[2], B, L, *outs_a)
+    outs_b, d_x = [z(R, 3 * D), z(R, D), z(R, D), torch.zeros((B, 8, D), device="cuda")], dev(d_x0)
+    ops.tagru_bwd(d_short, xd, tld, sld, whg, whc, tvec, plain[2], B, L, *outs_b, dkv=(d_kv, img_t, d_x))
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    ref = d_x0.astype(np.float64) + d_kv.double().cpu().numpy() @ Wkv.double().cpu().numpy().T
+    assert rel_err(d_x.cpu().numpy(), ref) < 2e-5
+    want = dev(d_x0)
+    ops.gemm(d_kv, Wkv, want, trans_b=True, epilogue=ops.EPI_ACCUM)
+    assert rel_err(d_x.cpu().numpy(), want.cpu().numpy()) < 2e-6
+
+
 @pytest.mark.parametrize("B,L", [(3, 5), (16, 50), (128, 50)])
 def test_tagru_fwd_bwd(ops, B, L):
     import oracle.mtam_oracle as O
@@ -1060,7 +1116,7 @@ def _weight_images(ops, W4, Wkv, Wx):
     buf = torch.zeros(ops.seq_chain_images_elems(n_kv, n_x), dtype=torch.bfloat16, device="cuda")
     for which, W in ((0, W4), (1, Wkv), (2, Wx)):
         if W is not None:
-            ops.split_weight_images(W, buf[ops.seq_chain_image_offset(which, n_kv):])
+            ops.split_weight_images(W, buf[ops.seq_chain_image_offset(which, n_x):])
     return buf
 
 
@@ -1178,7 +1234,7 @@ def test_seq_chain_bwd_matches_the_two_gemms(ops, R, n_kv):
     img_r = torch.zeros(n_img, dtype=torch.bfloat16, device="cuda")
     for which, W in ((0, W4), (1, Wkv), (2, Wx)):
         if W.size:
-            ops.split_weight_rows(dev(W), img_r[ops.seq_chain_image_offset(which, n_kv):])
+            ops.split_weight_rows(dev(W), img_r[ops.seq_chain_image_offset(which, n_x):])
     d_x, d_z, d_ic = dev(d_x0), torch.full((R, D), 9.0, device="cuda"), torch.full((R, 2 * D), 9.0, device="cuda")
     d_kv_d = dev(np.ascontiguousarray(d_kv)) if n_kv else None
     ops.seq_chain_bwd(dev(d_xproj), d_kv_d, dev(d_xt), dev(zr), R, d_x, d_z, d_ic, img_r)

@@ -540,9 +540,9 @@ def test_weight_images_follow_the_weights(hip_lib, tmp_path, optimizer):
     def fresh():
         n_img = p.wimg.numel()
         buf = torch.zeros(2 * n_img, dtype=torch.bfloat16, device="cuda")
-        n_kv = p.layout.segments["kv/w"].shape[1]
+        n_x = p.layout.segments["gru/wx"].shape[1]
         for which, name in enumerate(("dense4emb/w", "kv/w", "gru/wx")):
-            o = ops.seq_chain_image_offset(which, n_kv)
+            o = ops.seq_chain_image_offset(which, n_x)
             ops.split_weight_images(p.seg(name), buf[o:])
             ops.split_weight_rows(p.seg(name), buf[n_img + o:])
         return buf
