@@ -548,7 +548,9 @@ def main():
         # SURVEY.md 8(d), (3L+1)(D e + 4) + L D e per sequence of table rows + ids, plus what it must write.
         t_fused, fused = None, None
         if args.model == "MTAM" and args.score_dtype == "f32" and getattr(bt, "fused_gather", False):
-            kvw, kvb = (p.seg("kv/w"), p.seg("kv/b")) if p.cfg["keys"] == "x" and p.cfg["attention"] else (None, None)
+            # (the K/V projection is part of this launch only when it does not ride with the GRU launch)
+            kv_here = p.cfg["keys"] == "x" and p.cfg["attention"] and not p._kv_role_on()
+            kvw, kvb = (p.seg("kv/w"), p.seg("kv/b")) if kv_here else (None, None)
 
             def fused_fn(i):
                 f = ids[i % len(ids)]
@@ -571,6 +573,8 @@ def main():
                      "arith": "6 bf16-MFMA terms per fp32 product (split operands)" if x3 else "fp32 MFMA",
                      "traffic": None, "flops_per_launch": flops, "us_per_launch": t_fused * 1e6,
                      "lookup_bytes_per_launch_fused_bound": lookup_bytes,
+                     "kv_projection": "inside this launch" if kv_here else
+                                      "extra workgroups of the GRU launch (the CUs the recurrence leaves idle)",
                      "note": "the training step's embedding lookups run inside this kernel; the stand-alone gather "
                              "kernel of `roofline` is what mtam_emb_gather_fwd callers (PISTRec, bf16 mode) launch"}
         gb = gather_bytes_per_seq(L, D) * B_PER_GPU

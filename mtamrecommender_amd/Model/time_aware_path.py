@@ -373,6 +373,12 @@ class TimeAwarePath(object):
                 and bt.xw * D + self.wimg_n_kv <= ops.seq_chain_bwd_max_k()
                 and os.environ.get("MTAM_SEQ_CHAIN_BWD", "1") != "0")
 
+    def _kv_role_on(self):
+        """kv = relu(x Wkv + bkv) as extra workgroups of the GRU's forward launch (csrc/tagru.hip: kv_role) instead of
+        inside the fused projection kernel; MTAM_KV_ROLES=0 keeps it there."""
+        return (self.cfg["attention"] and self.cfg["keys"] == "x" and self.wimg is not None
+                and self.cfg["gru"] in ("time", "plain") and os.environ.get("MTAM_KV_ROLES", "1") != "0")
+
     def _dkv_role_on(self, bt):
         """d_x += d_kv . Wkv^T as extra workgroups of the GRU's backward launch (csrc/tagru.hip: dkv_role; one decoder
         block, keys = x, the stripe kernel behind it); MTAM_KV_ROLES=0 leaves the term in the stripe kernel."""
@@ -445,8 +451,7 @@ class TimeAwarePath(object):
         kv_from_x = cfg["attention"] and cfg["keys"] == "x"    # keys/values of every block (before the GRU)
         # ... computed by extra workgroups of the GRU launch, on the CUs the recurrence leaves idle, instead of by the
         # fused projection kernel (csrc/tagru.hip: kv_role; MTAM_KV_ROLES=0 keeps it in the projection kernel)
-        kv_role = (kv_from_x and self.wimg is not None and cfg["gru"] in ("time", "plain")
-                   and os.environ.get("MTAM_KV_ROLES", "1") != "0")
+        kv_role = self._kv_role_on()
         kv_in_chain = kv_from_x and not kv_role
         # dense4emb, the K/V projection and the GRU's input projection in ONE launch (a 32-row stripe of x
         # stays on its CU; 16-byte stores): 25.5 us against 35.4 us as three GEMMs at 6,400 rows.
