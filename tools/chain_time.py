@@ -1,4 +1,5 @@
-"""What would leaving the K/V work out of the two stripe kernels save?  (their launches with and without it)"""
+"""The two stripe kernels with and without the K/V work (what riding with the GRU launches saves), and the two
+products as launches of their own.  python3 tools/chain_time.py on a GPU box."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
