@@ -409,6 +409,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d in the environment but --gpus %d" % (world, args.gpus))
+    # MTAM_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): every rank on cuda:0, collectives over gloo -- RCCL refuses
+    # two ranks on one device.  Exercises launcher, rank code, exchanges and kernels with world > 1; not a measurement.
+    share_gpu = os.environ.get("MTAM_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     # MTAM_BENCH_FORCE_DP=1: run the multi-GPU code path (RCCL group, gradient exchange, barriers, max over
@@ -422,7 +427,10 @@ def main():
     use_dist = world > 1 or force_dp
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(device))
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -604,6 +612,8 @@ def main():
                       "fp32 matmul's error); fused forward projections: native fp32 MFMA; GRU / attention / "
                       "optimizer / lookups: fp32 VALU; evaluation scores: k-ordered fp32 fmaf chain"),
             "data": "synthetic", "ranks_seen": ranks_seen, "ms_per_step_by_rank": per_rank_ms,
+            "rehearsal": ("every rank on cuda:0, gloo collectives (MTAM_BENCH_SHARE_GPU=1): NOT a measurement"
+                          if share_gpu else None),
             "exchange": (None if not use_dist else
                          {"flat": "flat all-reduce of every gradient",
                           "sharded": "row-sharded item exchange (reduce-scatter + owned Adam + all-gather)",
