@@ -21,3 +21,17 @@ for k, d in L.items():
     assert d['ranks_seen'] == 2 and len(d['ms_per_step_by_rank']) == 2
 print('the three exchanges agree: loss', ref['loss_first'], '->', ref['loss_last'], '(2 ranks, 200,000 items, 13 steps)')
 PY
+# ... and four ranks (row ranges of a quarter each; five processes on the card)
+run flat4 python3 bench.py --gpus 4 --steps 6 --warmup 2 --no-scale-legs --items 100003 --dp-exchange flat
+run sharded4 python3 bench.py --gpus 4 --steps 6 --warmup 2 --no-scale-legs --items 100003 --dp-exchange sharded
+run sharded_scoring4 python3 bench.py --gpus 4 --steps 6 --warmup 2 --no-scale-legs --items 100003 --dp-exchange sharded-scoring
+python3 - <<PY
+import json
+L = {k: json.load(open('$OUT/${TAG}_%s.json' % k)) for k in ('flat4', 'sharded4', 'sharded_scoring4')}
+ref = L['flat4']
+for k, d in L.items():
+    for f in ('loss_first', 'loss_last'):
+        assert abs(d[f] - ref[f]) / abs(ref[f]) < 2e-5, (k, f, d[f], ref[f])
+    assert d['ranks_seen'] == 4
+print('the three exchanges agree: loss', ref['loss_first'], '->', ref['loss_last'], '(4 ranks, 100,003 items, 8 steps)')
+PY
