@@ -572,7 +572,20 @@ struct WeightGradArgs {
   GroupArgs g;
   ColsumGroup c;
   int gemm_blocks;
+  int xcd_order;      // 1: blocks walk the group's order XCD by XCD (xcd_swizzle); MTAM_WGRAD_XCD=0 turns it off
 };
+
+// XCD-aware order of a grouped split-K launch.  Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
+// one, each XCD has its own L2), and the group's natural order is problem-major, k-slice-major, tile-minor: the 12-24
+// tiles of ONE k-slice -- which read the same rows of both operands -- landed on 8 different L2s, every one of which
+// fetched its own copy: 126 MB per launch at the fabric for ~40 MB of operands (profiles/r03_pmc_step_v1.json), which
+// at the HBM / Infinity-Cache rate IS the launch's 25 us.  Swizzled, an XCD works through a CONTIGUOUS range of that
+// order -- a few whole k-slices -- and its L2 serves the re-reads (cdna_hip_programming.md T1, bijective form: the
+// blocks past the last multiple of 8 keep their place).  Speed only: any placement gives the same sums.
+__device__ __forceinline__ int xcd_swizzle(int bid, int n) {
+  const int n8 = n & ~7;
+  return bid < n8 ? (bid & 7) * (n8 >> 3) + (bid >> 3) : bid;
+}
 
 template <bool X3>
 __global__ __launch_bounds__(256) void weight_grads_kernel(WeightGradArgs wa) {
@@ -586,10 +599,11 @@ __global__ __launch_bounds__(256) void weight_grads_kernel(WeightGradArgs wa) {
     return;
   }
   const GroupArgs &ga = wa.g;
+  const int bid = wa.xcd_order ? xcd_swizzle(blockIdx.x, wa.gemm_blocks) : (int)blockIdx.x;
   int g = 0;
-  while (g + 1 < ga.n && (int)blockIdx.x >= ga.first[g + 1]) ++g;
+  while (g + 1 < ga.n && bid >= ga.first[g + 1]) ++g;
   const GemmArgs &p = ga.g[g];
-  const int local = blockIdx.x - ga.first[g];
+  const int local = bid - ga.first[g];
   const int tiles = p.tiles_n * ((p.M + BM - 1) / BM);
   gemm_tile<1, true, false, MTAM_EPI_ATOMIC, X3>(p, As, Bs, local % tiles, local / tiles);
 }
@@ -833,6 +847,11 @@ extern "C" int mtam_weight_grads(int n_gemm, const MtamGemmDesc *d, int n_colsum
   rc = fill_colsums(n_colsum, jobs, wa.c, cb);
   if (rc) return rc;
   wa.gemm_blocks = gb;
+  static const bool xcd_on = [] {
+    const char *e = getenv("MTAM_WGRAD_XCD");
+    return !(e && e[0] == '0');
+  }();
+  wa.xcd_order = xcd_on ? 1 : 0;
   if (split_enabled())
     hipLaunchKernelGGL(weight_grads_kernel<true>, dim3(gb + cb), dim3(256), 0, static_cast<hipStream_t>(stream), wa);
   else

@@ -48,6 +48,26 @@ def pmc(fetch_csv, write_csv):
     print(json.dumps(out, indent=1))
 
 
+def pmc_step(fetch_csv, write_csv, patterns):
+    """Per-kernel HBM-side bytes per launch (FETCH_SIZE doubled as in pmc(), WRITE_SIZE as is) for every kernel whose
+    name contains one of the comma-separated patterns: the training step's kernels under `bench.py`."""
+    pats = patterns.split(",")
+    out = collections.OrderedDict()
+    for counter, path in (("FETCH_SIZE", fetch_csv), ("WRITE_SIZE", write_csv)):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter and any(p in r["Kernel_Name"] for p in pats):
+                agg[short(r["Kernel_Name"]).split("(")[0]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            out.setdefault(k, {})[counter + "_KiB_avg"] = sum(v) / len(v)
+            out[k]["launches"] = len(v)
+    for k, d in out.items():
+        d["read_bytes_corrected"] = 2.0 * d.get("FETCH_SIZE_KiB_avg", 0.0) * 1024
+        d["write_bytes"] = d.get("WRITE_SIZE_KiB_avg", 0.0) * 1024
+        d["traffic_bytes"] = d["read_bytes_corrected"] + d["write_bytes"]
+    print(json.dumps(out, indent=1))
+
+
 def pmc_scale(out_dir, cases):
     """cases: "B512_V3709_zipf,..." -- reads OUT/pmc_fetch_<case>/ and OUT/pmc_write_<case>/ counter CSVs and
     prints {case: {"gather": {...}, "scatter": {...}}} (the file bench.py's roofline_at_scale reads)."""
@@ -69,6 +89,9 @@ def pmc_scale(out_dir, cases):
 
 
 if __name__ == "__main__":
+    if sys.argv[1] == "pmc_step":
+        pmc_step(sys.argv[2], sys.argv[3], sys.argv[4])
+        sys.exit(0)
     if sys.argv[1] == "pmc_scale":
         pmc_scale(sys.argv[2], sys.argv[3])
         sys.exit(0)
