@@ -593,9 +593,12 @@ def main():
         gru_model = None
         if args.model == "MTAM" and p.cfg["gru"] == "time":
             tvec = p.seg("gru/tvec")
+            # (the recurrence alone, weights from their register-order image as in the step; in the step the launch also
+            # carries the K/V projection on the CUs it leaves idle)
             t_gf = time_kernel(lambda: ops.tagru_fwd(bt.xproj, bt.x, fd["timelast_list"], fd["seq_length"],
                                                      p.seg("gru/wh_g"), p.seg("gru/wh_c"), tvec, B_PER_GPU, L, bt.hs,
-                                                     bt.short, bt.gru_save), torch, reps=20, replays=10)
+                                                     bt.short, bt.gru_save, w_image=p.gru_img), torch, reps=20,
+                               replays=10)
             t_gb = time_kernel(lambda: ops.tagru_bwd(bt.d_dec[0], bt.x, fd["timelast_list"], fd["seq_length"],
                                                      p.seg("gru/wh_g"), p.seg("gru/wh_c"), tvec, bt.gru_save,
                                                      B_PER_GPU, L, bt.d_xproj, bt.rh, bt.d_xt, bt.d_tvec_partial),

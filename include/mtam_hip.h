@@ -281,7 +281,16 @@ int mtam_tagru_bwd(const float *d_short, const float *d_hs, const float *x, cons
 int mtam_tagru_fwd_kv(const float *xproj, const float *x, const float *timelast, const int32_t *seq_len,
                       const float *wh_g, const float *wh_c, const float *tvec, int B, int L, float *hs,
                       float *short_out, float *save, const uint16_t *wkv_images, const float *bkv, int n_kv,
-                      float *kv_out, void *stream);
+                      float *kv_out, const float *gru_w_image, void *stream);
+/* gru_w_image (optional, NULL = the kernel brings wh_g / wh_c through LDS itself, ~5 us per launch): the recurrent
+ * weights in the order the forward's lanes hold them -- mtam_gru_weight_image_floats() floats, element (k, n) of the
+ * gate matrix wh_g [128, 256] (which = 0) / candidate matrix wh_c [128, 128] (which = 1) at
+ * mtam_gru_weight_image_pos(which, k, n); a lane's 96 weights are then 24 coalesced 16-byte loads that overlap the
+ * staging of the first chunk.  Written by mtam_gru_weight_image, or kept current by mtam_adam_images
+ * (MtamWeightImages.gru_which = 1 / 2 for wh_g / wh_c with `images` = the image). */
+int mtam_gru_weight_image_floats(void);
+int mtam_gru_weight_image_pos(int which, int k, int n);
+int mtam_gru_weight_image(const float *wh_g, const float *wh_c, float *image, void *stream);
 int mtam_tagru_bwd_dkv(const float *d_short, const float *d_hs, const float *x, const float *timelast,
                        const int32_t *seq_len, const float *wh_g, const float *wh_c, const float *tvec,
                        const float *save, int B, int L, float *d_xproj, float *rh, float *d_xt,
@@ -622,12 +631,14 @@ int mtam_adam_bf16copy(float *p, float *m, float *v, const float *g, size_t n, c
  * its weights already split and laid out as MFMA fragments (Embedding/...attention.py:95-103 dense4emb,
  * time_aware_attention.py:251-253 K / V, time_aware_rnn.py:243-256 input halves).  begin: first element of the
  * row-major [K, N] matrix in the flat space (multiple of 4; K multiple of 8, N of 4). */
-#define MTAM_MAX_WEIGHT_IMAGES 4
+#define MTAM_MAX_WEIGHT_IMAGES 6
 typedef struct {
   size_t begin;
   int K, N;
   uint16_t *images;   /* [K / 8][N][8] per term: the forward's B fragments (mtam_seq_chain_fwd) */
   uint16_t *images_r; /* the same layout of W^T: the backward's (mtam_seq_chain_bwd); may be NULL */
+  int gru_which;      /* 0: the bf16 images above.  1 / 2: W is the GRU's wh_g / wh_c and `images` is the fp32
+                         register-order image of mtam_gru_weight_image (images_r unused) */
 } MtamWeightImages;
 int mtam_adam_images(float *p, float *m, float *v, const float *g, size_t n, const float *scale, const float *hyper,
                      size_t sparse_begin, uint16_t *copy16, size_t copy_begin, const MtamWeightImages *w, int n_w,

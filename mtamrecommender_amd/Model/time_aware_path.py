@@ -336,7 +336,7 @@ class TimeAwarePath(object):
         (csrc/seq_chain.hip, split-bf16 products): one buffer [W4 | Wkv | Wx], re-written by the Adam launch that
         updates the weights (``mtam_adam_images``) and by ``refresh_weight_images`` whenever they change any other
         way.  MTAM_SEQ_CHAIN_X3=0 keeps the products on the fp32 MFMA."""
-        self.wimg, self.wimg_r, self.wimg_descs, self._wimg_parts = None, None, None, []
+        self.wimg, self.wimg_r, self.wimg_descs, self._wimg_parts, self.gru_img = None, None, None, [], None
         segs = self.layout.segments
         if "gru/wx" not in segs or self.cfg["gru"] == "seqrec" or os.environ.get("MTAM_SEQ_CHAIN_X3", "1") == "0":
             return
@@ -355,7 +355,15 @@ class TimeAwarePath(object):
             K, N = segs[name].shape
             o = ops.seq_chain_image_offset(which[name], n_x)
             self._wimg_parts.append((name, segs[name].offset, K, N, self.wimg[o:], self.wimg_r[o:]))
-        self.wimg_descs = ops.weight_image_descs([part[1:] for part in self._wimg_parts])
+        entries = [part[1:] for part in self._wimg_parts]
+        # ... and the GRU's recurrent weights in the order its forward's lanes hold them (csrc/gru_image.h): loaded
+        # straight into registers, the ~5 us LDS route of every forward launch gone (MTAM_GRU_WEIGHT_IMAGE=0 keeps it)
+        if self.cfg["gru"] in ("time", "plain") and os.environ.get("MTAM_GRU_WEIGHT_IMAGE", "1") != "0":
+            self.gru_img = torch.zeros(ops.gru_weight_image_floats(), dtype=torch.float32, device=self.device)
+            for name, kind in (("gru/wh_g", "gru_g"), ("gru/wh_c", "gru_c")):
+                K, N = segs[name].shape
+                entries.append((segs[name].offset, K, N, self.gru_img, None, kind))
+        self.wimg_descs = ops.weight_image_descs(entries)
 
     def _wimg_of(self, name):
         """(operand images, images of the transpose) of one weight matrix."""
@@ -389,6 +397,8 @@ class TimeAwarePath(object):
         for name, _, _, _, img, img_r in self._wimg_parts:
             ops.split_weight_images(self.seg(name), img)
             ops.split_weight_rows(self.seg(name), img_r)
+        if self.gru_img is not None:
+            ops.gru_weight_image(self.seg("gru/wh_g"), self.seg("gru/wh_c"), self.gru_img)
 
     def refresh_derived(self):
         """Everything kept beside the fp32 parameters and derived from them: call after ANY change of
@@ -506,7 +516,7 @@ class TimeAwarePath(object):
             kv_job = (self._wimg_of("kv/w")[0], self.seg("kv/b"), bt.kv) if kv_role else None
             ops.tagru_fwd(bt.xproj, bt.x, fd["timelast_list"], fd["seq_length"], self.seg("gru/wh_g"),
                           self.seg("gru/wh_c"), tvec, B, L, bt.hs, bt.short, bt.gru_save if training else None,
-                          kv=kv_job)
+                          kv=kv_job, w_image=self.gru_img)
         if cfg["short_ln"]:
             sl = self.seg("short/ln")
             ops.layer_norm_fwd(bt.short, sl[0], sl[1], 1e-12, B, bt.short_n, bt.short_ln_save if training else None)

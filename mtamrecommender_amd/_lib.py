@@ -55,7 +55,10 @@ SIGNATURES = {
     "mtam_seq_chain_bwd": (c_int, [P, c_int, P, c_int, P, P, c_int, P, P, P, P, P]),
     "mtam_tagru_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
     "mtam_tagru_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
-    "mtam_tagru_fwd_kv": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, c_int, P, P]),
+    "mtam_tagru_fwd_kv": (c_int, [P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, c_int, P, P, P]),
+    "mtam_gru_weight_image_floats": (c_int, []),
+    "mtam_gru_weight_image_pos": (c_int, [c_int, c_int, c_int]),
+    "mtam_gru_weight_image": (c_int, [P, P, P, P]),
     "mtam_tagru_bwd_dkv": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P, P, P, P, P, c_int, P, P, P]),
     "mtam_tagru_seqrec_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P]),
     "mtam_tagru_seqrec_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, P, P, P, P, P]),
@@ -126,7 +129,8 @@ class GemmDesc(ctypes.Structure):
 
 class WeightImages(ctypes.Structure):
     """MtamWeightImages (include/mtam_hip.h): one weight matrix of the flat space and where its bf16 images go."""
-    _fields_ = [("begin", c_size_t), ("K", c_int), ("N", c_int), ("images", c_void_p), ("images_r", c_void_p)]
+    _fields_ = [("begin", c_size_t), ("K", c_int), ("N", c_int), ("images", c_void_p), ("images_r", c_void_p),
+                ("gru_which", c_int)]
 
 
 class ColsumJob(ctypes.Structure):

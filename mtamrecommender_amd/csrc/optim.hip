@@ -5,6 +5,7 @@
 // (one 4096-float block per workgroup) so that V x D tables fill the chip.
 #include "common.h"
 #include "split_bf16.h"
+#include "gru_image.h"
 #include <stdlib.h>
 
 namespace {
@@ -245,6 +246,7 @@ struct AdamImages {
   size_t begin[MTAM_MAX_WEIGHT_IMAGES], end[MTAM_MAX_WEIGHT_IMAGES];
   int K[MTAM_MAX_WEIGHT_IMAGES], N[MTAM_MAX_WEIGHT_IMAGES];
   uint16_t *img[MTAM_MAX_WEIGHT_IMAGES], *img_r[MTAM_MAX_WEIGHT_IMAGES];
+  int gru_which[MTAM_MAX_WEIGHT_IMAGES];      // 1 / 2: the GRU forward's fp32 register-order image (csrc/tagru.hip)
 };
 template <bool COPY, bool NT>
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m,
@@ -310,6 +312,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
       const size_t e = e0 + (size_t)i * N;
       *reinterpret_cast<adam_f4 *>(p + e) = pe[i]; *reinterpret_cast<adam_f4 *>(m + e) = me[i];
       *reinterpret_cast<adam_f4 *>(v + e) = ve[i];
+    }
+    if (wi.gru_which[j]) {
+      // the GRU forward's image: the same fp32 values in the order its lanes hold them (mtam_gru_weight_image_pos)
+      float *gi = reinterpret_cast<float *>(wi.img[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gi[gru_image::pos(wi.gru_which[j] - 1, g4 * 4 + i, col + c)] = pe[i][c];
+      return;
     }
     const size_t term = (size_t)K * N;
     // forward images: half of a 16-byte piece (4 of its 8 consecutive k) per column and term
@@ -595,7 +606,11 @@ extern "C" int mtam_adam_images(float *p, float *m, float *v, const float *g, si
     wi.begin[j] = w[j].begin; wi.end[j] = w[j].begin + (size_t)w[j].K * w[j].N;
     for (int i = 0; i < j; ++i)
       MTAM_CHECK_ARG(wi.end[i] <= wi.begin[j] || wi.end[j] <= wi.begin[i], "adam_images: matrices %d and %d overlap", i, j);
+    MTAM_CHECK_ARG(w[j].gru_which == 0 || (w[j].K == MTAM_D && w[j].N == (w[j].gru_which == 1 ? 2 : 1) * MTAM_D &&
+                                           w[j].gru_which <= 2),
+                   "adam_images: matrix %d: gru_which 1 / 2 is the GRU's wh_g [128, 256] / wh_c [128, 128]", j);
     wi.K[j] = w[j].K; wi.N[j] = w[j].N; wi.img[j] = w[j].images; wi.img_r[j] = w[j].images_r;
+    wi.gru_which[j] = w[j].gru_which;
     wi.first_block[j + 1] = wi.first_block[j] + (unsigned)(((size_t)(w[j].K / 4) * (w[j].N / 4) + 255) / 256);
   }
   dim3 grid(wi.n_linear + wi.first_block[n_w]);

@@ -28,6 +28,7 @@
 #include "common.h"
 #include "split_bf16.h"
 #include "stripe_tile.h"
+#include "gru_image.h"
 
 // In-kernel stamps for tools/gru_lab.hip (a diagnostic build, -DMTAM_GRU_STAMPS): cycles per segment of a
 // step, summed per wave of workgroup 0 and written to a buffer of their own.  The product build has none.
@@ -179,7 +180,20 @@ struct FwdArgs {
   const float *kv_bias;
   float *kv_out;
   int kv_n;
+  // the recurrent weights in the order the forward's lanes hold them (gru_wimg_pos): 24 sixteen-byte pieces per
+  // thread, piece j of thread t at float4 index j * 512 + t; NULL = go through LDS (below)
+  const float *w_img;
 };
+
+constexpr int GRU_WIMG_FLOATS = gru_image::FLOATS;
+__device__ __forceinline__ int gru_wimg_pos(int which, int k, int n) { return gru_image::pos(which, k, n); }
+
+__global__ __launch_bounds__(256) void gru_weight_image_kernel(const float *__restrict__ wh_g,
+                                                               const float *__restrict__ wh_c, float *__restrict__ img) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < D * 2 * D) img[gru_wimg_pos(0, i / (2 * D), i % (2 * D))] = wh_g[i];
+  else if (i < D * 3 * D) img[gru_wimg_pos(1, (i - D * 2 * D) / D, (i - D * 2 * D) % D)] = wh_c[i - D * 2 * D];
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Work co-scheduled with the recurrence.  A GRU launch keeps 128 of the 256 CUs busy for ~46 us (one sample per
@@ -294,23 +308,38 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
   // memory each lane issued 48 eight-byte loads of 8 rows per wave instruction: 9.5 us of a 52 us kernel
   // (tools/gru_lab.hip with the loads skipped).  Rows are staged 257 / 129 floats apart so that the 8 row
   // groups of a wave's read fall on different banks.
+  // Round 3: with the image the optimizer launch keeps beside the weights (p.w_img: the same values in exactly this
+  // register order) a lane's 96 weights are 24 coalesced 16-byte loads, requested HERE and scaled into place behind
+  // the staging of the first chunk -- the ~5 us of the LDS route (three barriers, two LDS round trips) disappear
+  // into the shadow of the staging loads.
   f32x2 wra[8], wrb[8], wua[8], wub[8], wca[8], wcb[8];
-  constexpr int GP = 2 * D + 1, CP = D + 1;
-  stage_matrix_512<D, 2 * D, GP>(p.wh_g, stage, tid);
-  __syncthreads();
+  if (p.w_img) {            // raw values into the registers they stay in; scaled in place behind the staging
+    const float4 *wi = reinterpret_cast<const float4 *>(p.w_img) + tid;
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    const float *g0 = &stage[(16 * kp + 2 * kk) * GP + 2 * q2], *g1 = g0 + GP;
-    wra[kk] = f32x2{g0[0], g1[0]} * (-L2E_); wrb[kk] = f32x2{g0[1], g1[1]} * (-L2E_);
-    wua[kk] = f32x2{g0[D], g1[D]} * (-L2E_); wub[kk] = f32x2{g0[D + 1], g1[D + 1]} * (-L2E_);
-  }
-  __syncthreads();
-  stage_matrix_512<D, D, CP>(p.wh_c, stage, tid);
-  __syncthreads();
+    for (int kk = 0; kk < 8; ++kk) {
+      const float4 a = wi[kk * 512], b = wi[(8 + kk) * 512], c = wi[(16 + kk) * 512];
+      wra[kk] = f32x2{a.x, a.y}; wrb[kk] = f32x2{a.z, a.w};
+      wua[kk] = f32x2{b.x, b.y}; wub[kk] = f32x2{b.z, b.w};
+      wca[kk] = f32x2{c.x, c.y}; wcb[kk] = f32x2{c.z, c.w};
+    }
+  } else {
+    constexpr int GP = 2 * D + 1, CP = D + 1;
+    stage_matrix_512<D, 2 * D, GP>(p.wh_g, stage, tid);
+    __syncthreads();
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    const float *c0 = &stage[(16 * kp + 2 * kk) * CP + 2 * q2], *c1 = c0 + CP;
-    wca[kk] = f32x2{c0[0], c1[0]} * (-2.f * L2E_); wcb[kk] = f32x2{c0[1], c1[1]} * (-2.f * L2E_);
+    for (int kk = 0; kk < 8; ++kk) {
+      const float *g0 = &stage[(16 * kp + 2 * kk) * GP + 2 * q2], *g1 = g0 + GP;
+      wra[kk] = f32x2{g0[0], g1[0]} * (-L2E_); wrb[kk] = f32x2{g0[1], g1[1]} * (-L2E_);
+      wua[kk] = f32x2{g0[D], g1[D]} * (-L2E_); wub[kk] = f32x2{g0[D + 1], g1[D + 1]} * (-L2E_);
+    }
+    __syncthreads();
+    stage_matrix_512<D, D, CP>(p.wh_c, stage, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float *c0 = &stage[(16 * kp + 2 * kk) * CP + 2 * q2], *c1 = c0 + CP;
+      wca[kk] = f32x2{c0[0], c1[0]} * (-2.f * L2E_); wcb[kk] = f32x2{c0[1], c1[1]} * (-2.f * L2E_);
+    }
   }
   // lanes kp 0, 1 work on unit 2 q2, lanes kp 2, 3 on unit 2 q2 + 1 (kp >= 4: copies, never stored)
   const int q = 2 * q2 + ((kp >> 1) & 1);
@@ -384,6 +413,14 @@ __global__ __launch_bounds__(512) void tagru_fwd_kernel(FwdArgs p) {
     }
     __syncthreads();
     GRU_PHASE(3)        // time-gate inputs staged
+    if (p.w_img && t0 == 0) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        wra[kk] = wra[kk] * (-L2E_); wrb[kk] = wrb[kk] * (-L2E_);
+        wua[kk] = wua[kk] * (-L2E_); wub[kk] = wub[kk] * (-L2E_);
+        wca[kk] = wca[kk] * (-2.f * L2E_); wcb[kk] = wcb[kk] * (-2.f * L2E_);
+      }
+    }
 
     GRU_STAMP_START
     for (int s = 0; s < nch; ++s) {
@@ -763,15 +800,16 @@ extern "C" int mtam_tagru_fwd(const float *xproj, const float *x, const float *t
                               const float *tvec, int B, int L, float *hs, float *short_out,
                               float *save, void *stream) {
   return mtam_tagru_fwd_kv(xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save, nullptr, nullptr,
-                           0, nullptr, stream);
+                           0, nullptr, nullptr, stream);
 }
 
 extern "C" int mtam_tagru_fwd_kv(const float *xproj, const float *x, const float *timelast,
                                  const int32_t *seq_len, const float *wh_g, const float *wh_c,
                                  const float *tvec, int B, int L, float *hs, float *short_out,
                                  float *save, const uint16_t *wkv_images, const float *bkv, int n_kv, float *kv_out,
-                                 void *stream) {
+                                 const float *gru_w_image, void *stream) {
   MTAM_CHECK_ARG(B > 0 && L > 0, "tagru_fwd: B and L must be positive");
+  MTAM_CHECK_ARG(mtam_aligned16(gru_w_image), "tagru_fwd_kv: gru_w_image must be 16-byte aligned");
   MTAM_CHECK_ARG(!wkv_images || (bkv && kv_out && n_kv > 0 && n_kv % 32 == 0 && mtam_aligned16(wkv_images) &&
                                  mtam_aligned16(kv_out) && mtam_aligned16(x)),
                  "tagru_fwd_kv: the K/V role needs bkv, kv_out and n_kv a multiple of 32 (16-byte aligned operands)");
@@ -781,10 +819,25 @@ extern "C" int mtam_tagru_fwd_kv(const float *xproj, const float *x, const float
   MTAM_CHECK_ARG(mtam_aligned16(xproj) && mtam_aligned16(hs) && mtam_aligned16(save),
                  "tagru_fwd: xproj, hs and save must be 16-byte aligned");
   FwdArgs a{xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, 3 * D, hs, short_out, save, wkv_images, bkv, kv_out,
-            wkv_images ? n_kv : 0};
+            wkv_images ? n_kv : 0, gru_w_image};
   const int stripes = wkv_images ? (B * L + stripe::ROWS - 1) / stripe::ROWS : 0;
   hipLaunchKernelGGL(tagru_fwd_kernel, dim3(B + stripes), dim3(512), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("tagru_fwd");
+  return MTAM_OK;
+}
+
+extern "C" int mtam_gru_weight_image_floats(void) { return GRU_WIMG_FLOATS; }
+
+extern "C" int mtam_gru_weight_image_pos(int which, int k, int n) {
+  if (which < 0 || which > 1 || k < 0 || k >= D || n < 0 || n >= (which ? D : 2 * D)) return -1;
+  return gru_image::pos(which, k, n);
+}
+
+extern "C" int mtam_gru_weight_image(const float *wh_g, const float *wh_c, float *image, void *stream) {
+  MTAM_CHECK_ARG(wh_g && wh_c && image && mtam_aligned16(image), "gru_weight_image: bad arguments");
+  hipLaunchKernelGGL(gru_weight_image_kernel, dim3(D * 3 * D / 256), dim3(256), 0, static_cast<hipStream_t>(stream), wh_g,
+                     wh_c, image);
+  MTAM_CHECK_LAUNCH("gru_weight_image");
   return MTAM_OK;
 }
 

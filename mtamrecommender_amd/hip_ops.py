@@ -179,15 +179,25 @@ def emb_scatter_add_items_range(d_ic, ic, item_ids, seq_len, B, L, reg, g_item, 
     _lib.check(rc, "mtam_emb_scatter_add_bwd_range")
 
 
-def tagru_fwd(xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save, kv=None):
+def tagru_fwd(xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save, kv=None, w_image=None):
     """kv = (Wkv operand images, bkv, kv_out [B L, n_kv]): the K/V projection relu(x Wkv + bkv) rides in the same
-    launch as extra workgroups on the CUs the recurrence leaves idle."""
+    launch as extra workgroups on the CUs the recurrence leaves idle.  w_image: the recurrent weights in the lanes'
+    register order (``gru_weight_image``): loaded straight into registers instead of going through LDS."""
     lib = _lib.load()
     img, bkv, kv_out = kv if kv is not None else (None, None, None)
     rc = lib.mtam_tagru_fwd_kv(_p(xproj), _p(x), _p(timelast), _pi(seq_len), _p(wh_g), _p(wh_c), _p(tvec),
                                B, L, _p(hs), _p(short_out), _p(save), _pb(img) if img is not None else None, _p(bkv),
-                               kv_out.shape[1] if kv_out is not None else 0, _p(kv_out), _stream())
+                               kv_out.shape[1] if kv_out is not None else 0, _p(kv_out), _p(w_image), _stream())
     _lib.check(rc, "mtam_tagru_fwd")
+
+
+def gru_weight_image_floats():
+    return _lib.load().mtam_gru_weight_image_floats()
+
+
+def gru_weight_image(wh_g, wh_c, image):
+    """wh_g [128, 256], wh_c [128, 128] -> the forward's register-order image (one launch)."""
+    _lib.check(_lib.load().mtam_gru_weight_image(_p(wh_g), _p(wh_c), _p(image), _stream()), "mtam_gru_weight_image")
 
 
 def tagru_bwd(d_short, x, timelast, seq_len, wh_g, wh_c, tvec, save, B, L, d_xproj, rh, d_x,
@@ -447,6 +457,8 @@ def weight_image_descs(entries):
         begin, K, N, img = e[:4]
         arr[i].begin, arr[i].K, arr[i].N, arr[i].images = int(begin), int(K), int(N), img.data_ptr()
         arr[i].images_r = e[4].data_ptr() if len(e) > 4 and e[4] is not None else None
+        # a sixth element "gru_g" / "gru_c": W is the GRU's wh_g / wh_c, `img` the fp32 register-order image
+        arr[i].gru_which = {"gru_g": 1, "gru_c": 2}[e[5]] if len(e) > 5 and e[5] else 0
     return arr, len(entries)
 
 

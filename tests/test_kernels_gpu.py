@@ -375,6 +375,13 @@ def test_gru_launches_carry_the_kv_work(ops, B, L, n_kv):
     ops.tagru_fwd(xproj, xd, tld, sld, whg, whc, tvec, B, L, *ridden, kv=(img, bkv, kv))
     for a, b in zip(plain, ridden):
         assert torch.equal(a, b)
+    # ... and with the recurrent weights taken from their register-order image instead of through LDS: the same bits
+    w_image = torch.zeros(ops.gru_weight_image_floats(), device="cuda")
+    ops.gru_weight_image(whg, whc, w_image)
+    direct = [z(R, D), z(B, D), z(R, 5 * D)]
+    ops.tagru_fwd(xproj, xd, tld, sld, whg, whc, tvec, B, L, *direct, w_image=w_image)
+    for a, b in zip(plain, direct):
+        assert torch.equal(a, b)
     ref = np.maximum(x.astype(np.float64) @ Wkv.double().cpu().numpy() + bkv.double().cpu().numpy(), 0.0)
     assert rel_err(kv.cpu().numpy(), ref) < 2e-5
     want = z(R, n_kv)
@@ -1132,6 +1139,42 @@ def test_weight_images_layout_and_exactness(ops):
     assert np.array_equal(terms[0], dev(W).bfloat16().float().cpu().numpy())      # term 1 = round-to-nearest bf16
     total = terms[0].astype(np.float64) + terms[1] + terms[2]
     assert np.array_equal(total.astype(np.float32), W) and np.abs(total - W).max() <= 2.0 ** -24 * np.abs(W).max()
+
+
+def test_gru_weight_image_layout(ops, hip_lib):
+    """mtam_gru_weight_image: a permutation of wh_g [128, 256] and wh_c [128, 128] -- element (k, n) at
+    mtam_gru_weight_image_pos(which, k, n), every position hit exactly once -- and mtam_adam_images (gru_which 1 / 2)
+    keeps it current from the values it updates."""
+    rng = np.random.default_rng(2)
+    whg, whc = rng.standard_normal((D, 2 * D)).astype(np.float32), rng.standard_normal((D, D)).astype(np.float32)
+    n = ops.gru_weight_image_floats()
+    assert n == D * 3 * D
+    img = torch.full((n,), 7.0, device="cuda")
+    ops.gru_weight_image(dev(whg), dev(whc), img)
+    got = img.cpu().numpy()
+    pos_g = np.array([[hip_lib.mtam_gru_weight_image_pos(0, k, c) for c in range(2 * D)] for k in range(D)])
+    pos_c = np.array([[hip_lib.mtam_gru_weight_image_pos(1, k, c) for c in range(D)] for k in range(D)])
+    assert sorted(np.concatenate([pos_g.ravel(), pos_c.ravel()]).tolist()) == list(range(n))
+    assert np.array_equal(got[pos_g], whg) and np.array_equal(got[pos_c], whc)
+    assert hip_lib.mtam_gru_weight_image_pos(0, D, 0) == -1 and hip_lib.mtam_gru_weight_image_pos(1, 0, D) == -1
+    # kept current by the optimizer launch
+    blk = ops.adam_block()
+    total = 16 * blk
+    p0 = rng.standard_normal(total).astype(np.float32)
+    p0[64:64 + whg.size] = whg.ravel()
+    p0[40000:40000 + whc.size] = whc.ravel()
+    g, m0, v0 = rng.standard_normal(total).astype(np.float32), np.zeros(total, np.float32), np.full(total, 0.01, np.float32)
+    scale, hyper = dev(np.array([1.0, 1.0], np.float32)), dev(np.array([1e-2, 0.9, 0.999, 1e-8], np.float32))
+    p, m, v = dev(p0), dev(m0), dev(v0)
+    img2 = torch.zeros(n, device="cuda")
+    descs = ops.weight_image_descs([(64, D, 2 * D, img2, None, "gru_g"), (40000, D, D, img2, None, "gru_c")])
+    ops.adam_images(p, m, v, dev(g), total, scale, hyper, total, descs)
+    want = torch.zeros(n, device="cuda")
+    ops.gru_weight_image(p[64:64 + whg.size].view(D, 2 * D), p[40000:40000 + whc.size].view(D, D), want)
+    assert torch.equal(img2, want) and not torch.equal(p[64:64 + whg.size].cpu(), torch.from_numpy(whg.ravel()))
+    p_ref, m_ref, v_ref = dev(p0), dev(m0), dev(v0)
+    ops.adam(p_ref, m_ref, v_ref, dev(g), total, scale, hyper, total)
+    assert torch.equal(p, p_ref) and torch.equal(m, m_ref) and torch.equal(v, v_ref)
 
 
 def test_adam_rewrites_the_weight_images(ops):

@@ -547,19 +547,25 @@ def test_weight_images_follow_the_weights(hip_lib, tmp_path, optimizer):
             ops.split_weight_rows(p.seg(name), buf[n_img + o:])
         return buf
 
+    def fresh_gru():
+        img = torch.zeros_like(p.gru_img)
+        ops.gru_weight_image(p.seg("gru/wh_g"), p.seg("gru/wh_c"), img)
+        return img
+
     whole = lambda: torch.cat([p.wimg, p.wimg_r])
-    assert torch.equal(whole(), fresh())
+    assert torch.equal(whole(), fresh()) and torch.equal(p.gru_img, fresh_gru())
     w0 = p.seg("gru/wx").clone()
     for _ in range(3):
         model.train(model.sess, records, 1e-3)
-    assert not torch.equal(p.seg("gru/wx"), w0) and torch.equal(whole(), fresh())
+    assert not torch.equal(p.seg("gru/wx"), w0) and torch.equal(whole(), fresh()) and torch.equal(p.gru_img, fresh_gru())
     model.save(model.sess, global_step=1)
     arrays = model.get_variables()
     arrays["position_embedding/dense4emb/kernel"] = arrays["position_embedding/dense4emb/kernel"] * 1.5
+    arrays[[k for k in arrays if k.endswith("candidate/kernel")][0]] *= 0.5
     model.set_variables(arrays)
-    assert torch.equal(whole(), fresh())
+    assert torch.equal(whole(), fresh()) and torch.equal(p.gru_img, fresh_gru())
     model.restore(model.sess, str(tmp_path))
-    assert torch.equal(whole(), fresh())
+    assert torch.equal(whole(), fresh()) and torch.equal(p.gru_img, fresh_gru())
 
 
 def test_async_loss_is_logged_once_under_its_own_step(hip_lib, tmp_path):
