@@ -110,6 +110,22 @@ def pmc_scale_traffic(key, kernel):
         return None
 
 
+def pmc_step_traffic(kernel):
+    """Per-launch HBM-side bytes of one of the training step's kernels from the committed PMC passes over
+    `bench.py` itself (profiles/r*_pmc_step_*.json, tools/gpu_r3_pmc_step.sh); None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_*.json")))
+    if not files:
+        return None
+    try:
+        for name, row in json.load(open(files[-1])).items():
+            if kernel in name:
+                return float(row["traffic_bytes"])
+    except (KeyError, ValueError, OSError, TypeError):
+        pass
+    return None
+
+
 def emb_scale_legs(ops, torch, device, run_tables, reg):
     """`roofline_at_scale`: the stand-alone gather and scatter-add kernels (through their C entry points) at 512 and
     2,048 sequences per launch, L = 50, D = 128 -- the sizes at which the launch is bandwidth-bound rather than a
@@ -579,7 +595,8 @@ def main():
                      "achieved": issued / t_fused / 1e12, "peak": peak, "unit": "TFLOP/s",
                      "frac": issued / t_fused / 1e12 / peak, "fp32_equivalent_tflops": flops / t_fused / 1e12,
                      "arith": "6 bf16-MFMA terms per fp32 product (split operands)" if x3 else "fp32 MFMA",
-                     "traffic": None, "flops_per_launch": flops, "us_per_launch": t_fused * 1e6,
+                     "traffic": pmc_step_traffic("seq_chain_x3_kernel") if x3 and (L, B_PER_GPU) == (50, 128) else None,
+                     "flops_per_launch": flops, "us_per_launch": t_fused * 1e6,
                      "lookup_bytes_per_launch_fused_bound": lookup_bytes,
                      "kv_projection": "inside this launch" if kv_here else
                                       "extra workgroups of the GRU launch (the CUs the recurrence leaves idle)",
