@@ -290,7 +290,7 @@ class ShardedScoringExchange(ShardedItemExchange):
             f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
             R = bt.ic.shape[0]
             self._b[B] = dict(pred=f(G * B, D), tgt=torch.zeros(G * B, dtype=torch.int32, device=dev), lse_part=f(G * B),
-                              stats=f(2, G * B), lse=f(G * B), d_pred=f(G * B, D),
+                              stats=f(2, G * B), lse=f(G * B), m=f(G * B), d_pred=f(G * B, D),
                               d_ic=f(G, R, 2 * D), ic=f(G, R, 2 * D),
                               ids=torch.zeros((G, R), dtype=torch.int32, device=dev),
                               sl=torch.zeros((G, B), dtype=torch.int32, device=dev))
@@ -308,14 +308,17 @@ class ShardedScoringExchange(ShardedItemExchange):
         k.lse_range(E_rows, self.row_lo, w["pred"], w["tgt"], lse_part, tlogit)
         # the whole catalog's log-sum-exp: m = max_r lse_r, lse = m + log sum_r exp(lse_r - m); the target's logit
         # lives on exactly one rank
-        m = lse_part.clone()
+        m = w["m"]                          # (every buffer of the step is allocated once per batch size)
+        m.copy_(lse_part)
         dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
-        torch.exp(lse_part - m, out=w["stats"][0])
+        torch.sub(lse_part, m, out=w["stats"][0])
+        w["stats"][0].exp_()
         dist.all_reduce(w["stats"], op=dist.ReduceOp.SUM, group=self.group)
-        torch.add(m, torch.log(w["stats"][0]), out=w["lse"])
+        torch.log(w["stats"][0], out=w["lse"])
+        w["lse"].add_(m)
         own = slice(r * B, (r + 1) * B)
         bt.lse.copy_(w["lse"][own])
-        bt.ce.copy_(w["lse"][own] - w["stats"][1][own])
+        torch.sub(w["lse"][own], w["stats"][1][own], out=bt.ce)
         dE_rows = p.g_tab["item"][self.row_lo:self.row_hi]
         k.bwd_range(E_rows, self.row_lo, w["pred"], w["lse"], w["tgt"], 1.0 / p.gb(bt), w["d_pred"], dE_rows)
         dist.reduce_scatter_tensor(bt.d_pred, w["d_pred"], op=dist.ReduceOp.SUM, group=self.group)
