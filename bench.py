@@ -669,7 +669,7 @@ def main():
         }
         if gru_model is not None:
             result["gru_serial_model"] = gru_model
-        if not args.no_scale_legs and args.score_dtype == "f32":
+        if not args.no_scale_legs and args.score_dtype == "f32" and world == 1:      # (the other ranks would only wait)
             result["roofline_at_scale"] = emb_scale_legs(ops, torch, device, T, p.reg)
         if fused is not None:
             result["roofline_fused_forward"] = fused
