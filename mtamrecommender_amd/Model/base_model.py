@@ -81,6 +81,7 @@ class base_model(object):
         self.use_graph = os.environ.get("MTAM_HIP_GRAPH", "1") != "0"
         self._dp_mode = os.environ.get("MTAM_DP_GRAPH")       # None: decided at the first data-parallel step
         self._graphs = {}
+        self._feed_refs = {}        # pinned feed arenas whose address a captured step reads (kept alive with the graphs)
         # async_loss: train() hands back the loss of the PREVIOUS step (with the global_step it belongs to; nothing
         # on the first call) instead of blocking on this step's -- the reference's sess.run blocks (:159-164), and
         # with a blocking read-back the host cannot prepare batch t + 1 while the device runs step t.  Off by
@@ -364,6 +365,9 @@ class base_model(object):
         lr_off = bt.offsets["lr"][0]
         batch_data.arena[lr_off:lr_off + 1].view(torch.float32)[0] = float(np.float32(learning_rate))
         src = batch_data.arena
+        # a captured graph reads this address at every replay: the arena must outlive the graph (a freed pinned block
+        # could come back as someone else's memory under the same address)
+        self._feed_refs[src.data_ptr()] = src
         cur = self._loss_begin() if self.async_loss else -1
         host = self._loss_ring[cur][0] if cur >= 0 else None
 
