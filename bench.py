@@ -396,7 +396,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--score-dtype", default="f32", choices=["f32", "bf16"],
                     help="bf16: logits-free bf16-MFMA catalog scoring (BASELINE.json configs[4]); default fp32")
-    ap.add_argument("--dp-exchange", default=None, choices=["flat", "sharded", "sharded-scoring"],
+    ap.add_argument("--dp-exchange", default=None, choices=["flat", "sharded", "sharded-scoring", "sharded-table"],
                     help="data-parallel gradient exchange (default: by catalog size -- flat below 64 MiB of item "
                          "table, sharded above; sharded-scoring: the item table row-sharded for scoring too)")
     ap.add_argument("--launch-selftest", action="store_true",
@@ -525,6 +525,8 @@ def main():
         elapsed = data_parallel.max_over_ranks(elapsed, device)
 
     log("rank %d: timed region %.3f s for %d steps" % (rank, elapsed, args.steps))
+    if use_dist:
+        model._current_table()      # ("sharded-table": rank 0 evaluates below; bringing a replica up to date is a collective)
     loss_last = float(bt.loss[0].item())
     if not np.isfinite(loss_last):
         raise SystemExit("non-finite training loss")
@@ -638,7 +640,9 @@ def main():
                          {"flat": "flat all-reduce of every gradient",
                           "sharded": "row-sharded item exchange (reduce-scatter + owned Adam + all-gather)",
                           "sharded-scoring": "item table row-sharded for scoring too (all-gather pred, reduced lse and "
-                                             "d_pred, dE born sharded, slot exchange, owned Adam, all-gather)"}
+                                             "d_pred, dE born sharded, slot exchange, owned Adam, all-gather)",
+                          "sharded-table": "item table row-sharded for scoring AND left sharded (history rows fetched "
+                                           "from their owners, no all-gather of the updated rows)"}
                          [p.dp_exchange]),
             "config": {"workload": "%s training step, %s synthetic (%d items, %d categories, %d users), seq_len=%d "
                                    "emb=128 num_blocks=%d num_heads=%d, batch=%d per GPU"

@@ -233,6 +233,12 @@ int mtam_emb_scatter_add_bwd_range(const float *d_item_cat, const float *d_z, co
                                    int L, float reg, int with_user, float *g_item, int item_rows, float *g_cat,
                                    int cat_rows, float *g_pos, int pos_rows, float *g_user, int user_rows,
                                    float *slot_sq_partial, int item_lo, int item_hi, int item_only, void *stream);
+/* out [n, 128]: row ids[i] of the catalog if it lies in the range [row0, row0 + nrows) that table_rows holds (its
+ * first row is catalog row row0), else zeros.  Data-parallel "sharded-table" exchange: the owners' rows of every
+ * rank's history ids, summed by a reduce-scatter (each row has exactly one owner), replace a replicated item table as
+ * the source of the embedding lookups (Embedding/Behavior_embedding_time_aware_attention.py:68-75). */
+int mtam_rows_gather_range(const float *table_rows, int row0, int nrows, const int32_t *ids, long n, float *out,
+                           void *stream);
 
 /* ----------------------------------------------------------- time-aware GRU
  * dynamic_rnn(TimeAwareGRUCell_decay_new) + gather_indexes(seq_len - 2):

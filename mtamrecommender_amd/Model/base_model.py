@@ -278,6 +278,9 @@ class base_model(object):
         if getattr(p, "sharded_scoring", None) is not None:
             # scoring row-sharded over the ranks: forward to pred (graph), the two scoring passes with their small
             # collectives (eager), backward from d_pred (graph), exchange + update (eager)
+            if not p.sharded_scoring.replicate_table:       # "sharded-table": the batch's item rows from their owners
+                p.row_iota(bt)
+                p.sharded_scoring.fetch_history_rows(bt)
             self._run("train_pre", bt, p.forward_to_pred_kernels)
             p.sharded_scoring.score(bt)
             self._run("train_post", bt, p.backward_from_pred_kernels)
@@ -440,9 +443,17 @@ class base_model(object):
         ev.synchronize()
         return float(host[0])
 
+    def _current_table(self):
+        """Data-parallel "sharded-table": bring this replica's item rows up to date (a collective: every rank calls it
+        at the same point -- evaluation and checkpoints are replicated / rank-0 operations of the same loop)."""
+        ex = getattr(self.path, "sharded_scoring", None)
+        if ex is not None and not ex.replicate_table:
+            ex.sync_item_table()
+
     def metrics_topK(self, sess, batch_data, global_step, topk):
         """hr/ndcg @ 1, 5, 10, 30, 50 over the full catalog (reference :188-213;
         the ``topk`` argument is accepted and ignored there too)."""
+        self._current_table()
         p = self.path
         bt, result_item = self._load(batch_data)
         self._run("eval", bt, p.eval_kernels)
@@ -457,6 +468,7 @@ class base_model(object):
 
     def recall_at(self, sess, batch_data, k=20):
         """Recall@k per batch (BASELINE.json's metric; the reference never computes K=20)."""
+        self._current_table()
         p = self.path
         bt, tgt = self._load(batch_data)
         self._run("eval", bt, p.eval_kernels)

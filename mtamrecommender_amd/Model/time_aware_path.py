@@ -455,6 +455,12 @@ class TimeAwarePath(object):
         predict_behavior_emb (slab-wise evaluation scores the catalog itself)."""
         B, R, L, NB, H = bt.B, bt.R, self.L, self.NB, self.H
         fd, T, cfg = bt.feed, self.tables, self.cfg
+        item_table, item_ids = T["item"], fd["item_list"]
+        if training and self.sharded_scoring is not None and not self.sharded_scoring.replicate_table:
+            # "sharded-table" data parallelism: this rank's copy of the item rows it does not own is stale; the rows of
+            # the batch's history ids were fetched from their owners (ShardedScoringExchange.fetch_history_rows) and
+            # are looked up by position
+            item_table, item_ids = bt.item_rows, self.row_iota(bt)
         # a training step's first kernel also clears its gradient accumulators
         clear = (self.zero_prefix, bt.d_clear if cfg["keys"] == "gru" else bt.d_pred.view(-1)) if training else ()
         keys = bt.hs if cfg["keys"] == "gru" else bt.x        # user_history: what the decoder attends over
@@ -472,7 +478,7 @@ class TimeAwarePath(object):
         # rows only in training (dense4emb's weight gradient reads them).  MTAM_FUSED_GATHER=0 keeps the gather kernel.
         bt.fused_gather = chain and self.item16 is None and os.environ.get("MTAM_FUSED_GATHER", "1") != "0"
         if bt.fused_gather:
-            ops.seq_chain_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
+            ops.seq_chain_gather_fwd(item_table, T["category"], T["position"], T["user"], item_ids,
                                      fd["category_list"], fd["position_list"], fd["user_id"], B, L, 1,
                                      self.seg("dense4emb/w"),
                                      self.seg("kv/w") if kv_in_chain else None, self.seg("kv/b") if kv_in_chain else None,
@@ -481,7 +487,7 @@ class TimeAwarePath(object):
                                      w_images=self.wimg)
             bt.l2_live = bt.l2_fused          # 4 sums per 32-row stripe: what the loss reduction has to read
         else:
-            ops.emb_gather_fwd(T["item"], T["category"], T["position"], T["user"], fd["item_list"],
+            ops.emb_gather_fwd(item_table, T["category"], T["position"], T["user"], item_ids,
                                fd["category_list"], fd["position_list"], fd["user_id"], B, L, 1,
                                bt.ic, bt.pos, bt.user, bt.l2_partial, clear=clear, item16=self.item16)
             bt.l2_live = bt.l2_partial
@@ -725,6 +731,13 @@ class TimeAwarePath(object):
 
     # the two halves of a step under data-parallel row-sharded scoring (the scoring passes and their collectives run
     # between them: data_parallel.ShardedScoringExchange.score)
+    def row_iota(self, bt):
+        """0 .. B L - 1 (int32): the "ids" of pre-fetched item rows; also allocates ``bt.item_rows`` [B L, 128]."""
+        if getattr(bt, "iota", None) is None:
+            bt.iota = torch.arange(bt.R, dtype=torch.int32, device=self.device)
+            bt.item_rows = torch.zeros((bt.R, D), dtype=torch.float32, device=self.device)
+        return bt.iota
+
     def forward_to_pred_kernels(self, bt):
         self.forward(bt, training=True, score=False)
 
@@ -734,6 +747,9 @@ class TimeAwarePath(object):
     def train_kernels(self, bt):
         """Everything between feed upload and loss read-back; capturable."""
         if self.sharded_scoring is not None:
+            if not self.sharded_scoring.replicate_table:
+                self.row_iota(bt)
+                self.sharded_scoring.fetch_history_rows(bt)
             self.forward_to_pred_kernels(bt)
             self.sharded_scoring.score(bt)
             self.backward_from_pred_kernels(bt)

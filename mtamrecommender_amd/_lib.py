@@ -43,6 +43,7 @@ SIGNATURES = {
                                                P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
     "mtam_emb_scatter_add_bwd_range": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
                                                P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P]),
+    "mtam_rows_gather_range": (c_int, [P, c_int, c_int, P, ctypes.c_long, P, P]),
     "mtam_seq_chain_gather_partials": (c_int, [c_int, c_int]),
     "mtam_seq_chain_gather_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
                                           P, P, P, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P, P, c_size_t, P,

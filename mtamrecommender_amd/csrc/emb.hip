@@ -408,6 +408,22 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
   if (lane == 0) p.sq_partial[blockIdx.x * WPB + wave_in_block] = sq;
 }
 
+// Rows of a ROW RANGE of a table, by catalog row number: out[i] = table_rows[ids[i] - row0] if the range holds row
+// ids[i], else zeros.  Data-parallel training with the item table sharded by rows (data_parallel.py, "sharded-table"):
+// every rank runs this over the ids of ALL ranks and a reduce-scatter of the results hands each rank the rows of its
+// own batch -- every row comes from exactly one owner, so the sum IS the row.  Half a wave per row, 16 bytes per lane.
+__global__ __launch_bounds__(256) void rows_gather_range_kernel(const float *__restrict__ table_rows, int row0,
+                                                                int nrows, const int32_t *__restrict__ ids, long n,
+                                                                float *__restrict__ out) {
+  const long i = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (i >= n) return;
+  const int li = threadIdx.x & 31;
+  const int t = ids[i] - row0;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t >= 0 && t < nrows) v = *reinterpret_cast<const float4 *>(table_rows + (size_t)t * D + 4 * li);
+  *reinterpret_cast<float4 *>(out + (size_t)i * D + 4 * li) = v;
+}
+
 int gather_waves(int B, int L) {
   const int R = B * L;
   const int total = R + (R + B + 1) / 2;
@@ -421,6 +437,16 @@ int scatter_work_blocks(int B, int L) {
 }
 
 }  // namespace
+
+extern "C" int mtam_rows_gather_range(const float *table_rows, int row0, int nrows, const int32_t *ids, long n,
+                                      float *out, void *stream) {
+  MTAM_CHECK_ARG(table_rows && ids && out && nrows > 0 && row0 >= 0 && n > 0, "rows_gather_range: bad arguments");
+  MTAM_CHECK_ARG(mtam_aligned16(table_rows) && mtam_aligned16(out), "rows_gather_range: rows must be 16-byte aligned");
+  hipLaunchKernelGGL(rows_gather_range_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), table_rows, row0, nrows, ids, n, out);
+  MTAM_CHECK_LAUNCH("rows_gather_range");
+  return MTAM_OK;
+}
 
 extern "C" int mtam_emb_gather_partials(int B, int L) { return ((gather_waves(B, L) + 3) / 4) * 4; }
 

@@ -48,7 +48,7 @@ def allreduce_gradients(buffers, group=None):
         dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
 
 
-EXCHANGES = ("flat", "sharded", "sharded-scoring")
+EXCHANGES = ("flat", "sharded", "sharded-scoring", "sharded-table")
 
 
 def attach(path, world_size, group=None, force=False, shard_items=None, exchange=None):
@@ -76,10 +76,11 @@ def attach(path, world_size, group=None, force=False, shard_items=None, exchange
     if exchange == "sharded":
         path.sharded = ShardedItemExchange(path, max(world_size, 1), rank, group)
         return
-    if exchange == "sharded-scoring":
+    if exchange in ("sharded-scoring", "sharded-table"):
         if not path.logits_free32:
-            raise ValueError("sharded-scoring runs on the fp32 logits-free scoring kernels (score_dtype 'f32')")
-        path.sharded_scoring = ShardedScoringExchange(path, max(world_size, 1), rank, group)
+            raise ValueError("%s runs on the fp32 logits-free scoring kernels (score_dtype 'f32')" % exchange)
+        path.sharded_scoring = ShardedScoringExchange(path, max(world_size, 1), rank, group,
+                                                      replicate_table=exchange == "sharded-scoring")
         return
 
     # The reported loss is a sum over ranks too (reg * l2 is a plain sum, the cross entropy a mean over the GLOBAL
@@ -201,8 +202,12 @@ class ShardedItemExchange(object):
         if self.hi_true > self.lo:
             k.adam(p.flat_p[self.lo:self.hi_true], p.flat_m[self.lo:self.hi_true], p.flat_v[self.lo:self.hi_true],
                    p.flat_g[self.lo:self.hi_true], p.scale, p.adam_state, 0)
-        self.all_gather_item_rows()
+        self.publish_item_rows()
         p.refresh_derived()
+
+    def publish_item_rows(self):
+        """After the update: every replica gets every owner's rows."""
+        self.all_gather_item_rows()
 
     def exchange_and_apply(self, bt):
         if self.p.optimizer != "adam":
@@ -235,6 +240,9 @@ class HipScoringKernels(HipStepKernels):
         Bg, V = pred_all.shape[0], E_rows.shape[0]
         d_pred_all.zero_()
         self.ops.score32_bwd(E_rows, pred_all, lse_all, tgt_all, Bg, V, scale, d_pred_all, dE_rows, None, row0=row0)
+
+    def gather_owned(self, E_rows, row0, ids, out):
+        self.ops.rows_gather_range(E_rows, row0, ids, out)
 
     def scatter_items(self, d_ic, ic, item_ids, seq_len, B, L, reg, g_item, rows):
         n = self.ops.emb_scatter_partials(B, L)
@@ -273,9 +281,17 @@ class ShardedScoringExchange(ShardedItemExchange):
     replicated update, a 1-rank RCCL test through the real kernels against the single-GPU step.
     """
 
-    def __init__(self, path, world, rank, group=None, kernels=None):
+    def __init__(self, path, world, rank, group=None, kernels=None, replicate_table=True):
         super(ShardedScoringExchange, self).__init__(path, world, rank, group,
                                                      kernels if kernels is not None else HipScoringKernels(path))
+        # replicate_table=False ("sharded-table"): the updated rows are NOT all-gathered.  A rank's copy of the rows it
+        # does not own goes stale; the embedding lookups take their item rows from the owners instead
+        # (fetch_history_rows: all-gather of the ranks' history ids, every rank looks its own rows up for ALL of them,
+        # a reduce-scatter of the [G B L, 128] result -- each row has one owner, so the sum is the row -- hands every
+        # rank the rows of its own batch: 26 MB at 8 ranks of 128 x 50 against the 4.5 GB all-gather at 10 M items).
+        # sync_item_table() brings a replica up to date for evaluation and checkpoints.
+        self.replicate_table = bool(replicate_table)
+        self.table_current = True
         self.rows_per_rank = path.item_rows_pad // world
         self.row_lo = rank * self.rows_per_rank
         self.row_hi = max(self.row_lo, min(self.row_lo + self.rows_per_rank, path.item_rows))   # rows that exist
@@ -286,15 +302,30 @@ class ShardedScoringExchange(ShardedItemExchange):
     def _buffers(self, bt):
         B = bt.B
         if B not in self._b:
-            G, dev = self.world, bt.pred.device
+            G, dev = self.world, self.p.flat_p.device
             f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-            R = bt.ic.shape[0]
+            R = B * self.p.L
             self._b[B] = dict(pred=f(G * B, D), tgt=torch.zeros(G * B, dtype=torch.int32, device=dev), lse_part=f(G * B),
                               stats=f(2, G * B), lse=f(G * B), m=f(G * B), d_pred=f(G * B, D),
-                              d_ic=f(G, R, 2 * D), ic=f(G, R, 2 * D),
+                              d_ic=f(G, R, 2 * D), ic=f(G, R, 2 * D), rows_all=None if self.replicate_table else f(G * R, D),
                               ids=torch.zeros((G, R), dtype=torch.int32, device=dev),
                               sl=torch.zeros((G, B), dtype=torch.int32, device=dev))
         return self._b[B]
+
+    # ---- before the forward ("sharded-table")
+    def fetch_history_rows(self, bt):
+        """bt.item_rows [B L, 128] <- the item rows of this rank's history ids, each from its owner."""
+        p, k, w = self.p, self.k, self._buffers(bt)
+        dist.all_gather_into_tensor(w["ids"].view(-1), bt.feed["item_list"].reshape(-1), group=self.group)
+        k.gather_owned(p.tables["item"][self.row_lo:self.row_hi], self.row_lo, w["ids"].view(-1), w["rows_all"])
+        dist.reduce_scatter_tensor(bt.item_rows, w["rows_all"], op=dist.ReduceOp.SUM, group=self.group)
+
+    def sync_item_table(self):
+        """All-gather the owners' rows into every replica ("sharded-table": before evaluation / a checkpoint)."""
+        if not self.table_current:
+            self.all_gather_item_rows()
+            self.p.refresh_derived()
+            self.table_current = True
 
     # ---- between the two halves of the step
     def score(self, bt):
@@ -331,7 +362,8 @@ class ShardedScoringExchange(ShardedItemExchange):
         # (outputs as the concatenation along dim 0 of the ranks' inputs: the shape both backends accept)
         dist.all_gather_into_tensor(w["d_ic"].view(-1, 2 * D), bt.d_ic, group=self.group)
         dist.all_gather_into_tensor(w["ic"].view(-1, 2 * D), bt.ic, group=self.group)
-        dist.all_gather_into_tensor(w["ids"].view(-1), bt.feed["item_list"].reshape(-1), group=self.group)
+        if self.replicate_table:            # ("sharded-table": fetch_history_rows has gathered the ids already)
+            dist.all_gather_into_tensor(w["ids"].view(-1), bt.feed["item_list"].reshape(-1), group=self.group)
         dist.all_gather_into_tensor(w["sl"].view(-1), bt.feed["seq_length"], group=self.group)
         for src in range(self.world):
             if src != self.rank:
@@ -343,6 +375,12 @@ class ShardedScoringExchange(ShardedItemExchange):
             raise NotImplementedError("the row-sharded exchange is built for Adam (the reference's default optimizer)")
         self.exchange(bt)
         self.apply(bt)
+
+    def publish_item_rows(self):
+        if self.replicate_table:
+            self.all_gather_item_rows()
+        else:
+            self.table_current = False      # "sharded-table": the replicas' foreign rows are stale from here on
 
 
 def broadcast_parameters(path, src=0, group=None):

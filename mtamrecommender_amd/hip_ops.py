@@ -179,6 +179,13 @@ def emb_scatter_add_items_range(d_ic, ic, item_ids, seq_len, B, L, reg, g_item, 
     _lib.check(rc, "mtam_emb_scatter_add_bwd_range")
 
 
+def rows_gather_range(table_rows, row0, ids, out):
+    """out[i] = table_rows[ids[i] - row0] where the range [row0, row0 + len(table_rows)) holds catalog row ids[i],
+    zeros elsewhere."""
+    _lib.check(_lib.load().mtam_rows_gather_range(_p(table_rows), int(row0), table_rows.shape[0], _pi(ids), ids.numel(),
+                                                  _p(out), _stream()), "mtam_rows_gather_range")
+
+
 def tagru_fwd(xproj, x, timelast, seq_len, wh_g, wh_c, tvec, B, L, hs, short_out, save, kv=None, w_image=None):
     """kv = (Wkv operand images, bkv, kv_out [B L, n_kv]): the K/V projection relu(x Wkv + bkv) rides in the same
     launch as extra workgroups on the CUs the recurrence leaves idle.  w_image: the recurrent weights in the lanes'

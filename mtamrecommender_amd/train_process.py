@@ -200,6 +200,7 @@ class Train_main_process(object):
         return avg
 
     def save_model(self):
+        self.model._current_table()      # (data-parallel "sharded-table": a collective, every rank takes part)
         if self.rank == 0:
             self.model.save(self.sess, self.global_step)
 

@@ -211,6 +211,12 @@ class _TorchScoringKernels(_TorchStepKernels):
         d_pred_all.copy_(G @ E_rows)
         dE_rows.copy_(G.t() @ pred_all)
 
+    def gather_owned(self, E_rows, row0, ids, out):
+        t = ids.long() - row0
+        owned = (t >= 0) & (t < E_rows.shape[0])
+        out.zero_()
+        out[owned] = E_rows[t[owned]]
+
     def scatter_items(self, d_ic, ic, item_ids, seq_len, B, L, reg, g_item, rows):
         D = 128
         live = (torch.arange(L)[None, :] < seq_len[:, None]).reshape(-1)
@@ -246,7 +252,7 @@ def _toy_loss(E, W, ids, sl, tgt, reg, global_batch):
     return ce.sum() / global_batch + reg * 0.5 * (rows ** 2).sum(), pred, ce
 
 
-def _scoring_worker(rank, world, port, out_dir):
+def _scoring_worker(rank, world, port, out_dir, replicate_table, n_steps):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -264,88 +270,102 @@ def _scoring_worker(rank, world, port, out_dir):
     ref = _FakePath(n_dense=D * D, small_rows=37, item_rows=V, seed=1)
     ref.world_size = world
     small = slice(D * D, off)
-    gens = [torch.Generator().manual_seed(500 + r) for r in range(world)]
-    small_g = [torch.round(torch.randn(off - D * D, generator=g) * 0.02 * 4096) / 4096 for g in gens]
     k = _TorchScoringKernels()
     lr = torch.tensor([1e-3])
-
-    # ---- the replicated update: the whole batch on one replica
-    E0 = ref.flat_p[off:off + V * D].view(V, D).clone().requires_grad_(True)
-    W0 = ref.flat_p[:D * D].view(D, D).clone().requires_grad_(True)
-    every = [_toy_inputs(r, B, L, V) for r in range(world)]
-    ids_all, sl_all, tgt_all = (torch.cat([e[i] for e in every]) for i in range(3))
-    loss_ref, _, ce_ref = _toy_loss(E0, W0, ids_all, sl_all, tgt_all, ref.reg, world * B)
-    loss_ref.backward()
-    ref.flat_g[:D * D] = W0.grad.reshape(-1)
-    ref.flat_g[small] = sum(small_g)
-    ref.flat_g[off:off + V * D] = E0.grad.reshape(-1)
-    sq = torch.zeros(1, dtype=torch.float64)
-    k.sq_sum(ref.flat_g[:ref.n_total], 1.0, sq, False)
-    k.clip_scale(sq, ref.clip, ref.scale, lr, ref.adam_state)
-    k.adam(ref.flat_p[:ref.n_total], ref.flat_m[:ref.n_total], ref.flat_v[:ref.n_total], ref.flat_g[:ref.n_total],
-           ref.scale, ref.adam_state, ref.n_dense)
-
-    # ---- the row-sharded step on this rank's slice of the batch
-    ex = data_parallel.ShardedScoringExchange(path, world, rank, kernels=k)
+    ex = data_parallel.ShardedScoringExchange(path, world, rank, kernels=k, replicate_table=replicate_table)
     assert ex.row_lo == rank * (path.item_rows_pad // world) and ex.row_hi <= V
-    ids, sl, tgt = every[rank]
-    bt = _ToyBatch()
-    bt.B = B
-    bt.feed = {"lr": lr, "target_item_id": tgt, "item_list": ids, "seq_length": sl}
-    bt.loss, bt.lse, bt.ce, bt.d_pred = torch.zeros(3), torch.zeros(B), torch.zeros(B), torch.zeros(B, D)
-    # forward to pred (the part of the step before the scoring passes)
-    E = path.tables["item"].clone().requires_grad_(True)
-    W = path.flat_p[:D * D].view(D, D).clone().requires_grad_(True)
-    rows = E[ids.long()]
-    live = (torch.arange(L)[None, :] < sl[:, None]).float()
-    pred = torch.tanh((rows * live[:, :, None]).sum(1) @ W)
-    bt.pred = pred.detach().clone()
-    bt.ic = torch.cat([rows.detach().reshape(B * L, D), torch.zeros(B * L, D)], 1).contiguous()
-    ex.score(bt)
-    # backward from d_pred: dense gradient, the looked-up rows' gradients, the rank's own slots into its own rows
-    pred.backward(bt.d_pred)
-    path.flat_g[:D * D] = W.grad.reshape(-1)
-    path.flat_g[small] = small_g[rank]
-    # (E.grad is dense here only because autograd has no other way to hand the looked-up rows' gradient over)
-    d_rows = torch.zeros(B * L, D)
-    flat_ids = ids.reshape(-1).long()
-    seen = {}
-    for slot in range(B * L):                      # one slot per id carries the id's whole (summed) gradient
-        i = int(flat_ids[slot])
-        if bool(live.reshape(-1)[slot]) and i not in seen:
-            seen[i] = slot
-            d_rows[slot] = E.grad[i]
-    bt.d_ic = torch.cat([d_rows, torch.zeros(B * L, D)], 1).contiguous()
-    bt.l2 = 0.5 * float((rows.detach() ** 2).sum())            # tf.nn.l2_loss: half the sum of squares
-    k.scatter_items(bt.d_ic, bt.ic, ids.reshape(-1), sl, B, L, path.reg, path.g_tab["item"], (ex.row_lo, ex.row_hi))
-    ex.exchange_and_apply(bt)
+    err = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    loss_err = ce_err = 0.0
+    for step in range(n_steps):
+        gens = [torch.Generator().manual_seed(500 + 10 * step + r) for r in range(world)]
+        small_g = [torch.round(torch.randn(off - D * D, generator=g) * 0.02 * 4096) / 4096 for g in gens]
+        every = [_toy_inputs(r, B, L, V, seed=7 + step) for r in range(world)]
+        # ---- the replicated update: the whole batch on one replica
+        E0 = ref.flat_p[off:off + V * D].view(V, D).clone().requires_grad_(True)
+        W0 = ref.flat_p[:D * D].view(D, D).clone().requires_grad_(True)
+        ids_all, sl_all, tgt_all = (torch.cat([e[i] for e in every]) for i in range(3))
+        loss_ref, _, ce_ref = _toy_loss(E0, W0, ids_all, sl_all, tgt_all, ref.reg, world * B)
+        loss_ref.backward()
+        ref.flat_g.zero_()
+        ref.flat_g[:D * D] = W0.grad.reshape(-1)
+        ref.flat_g[small] = sum(small_g)
+        ref.flat_g[off:off + V * D] = E0.grad.reshape(-1)
+        sq = torch.zeros(1, dtype=torch.float64)
+        k.sq_sum(ref.flat_g[:ref.n_total], 1.0, sq, False)
+        k.clip_scale(sq, ref.clip, ref.scale, lr, ref.adam_state)
+        k.adam(ref.flat_p[:ref.n_total], ref.flat_m[:ref.n_total], ref.flat_v[:ref.n_total], ref.flat_g[:ref.n_total],
+               ref.scale, ref.adam_state, ref.n_dense)
+
+        # ---- the row-sharded step on this rank's slice of the batch
+        ids, sl, tgt = every[rank]
+        bt = _ToyBatch()
+        bt.B = B
+        bt.feed = {"lr": lr, "target_item_id": tgt, "item_list": ids, "seq_length": sl}
+        bt.loss, bt.lse, bt.ce, bt.d_pred = torch.zeros(3), torch.zeros(B), torch.zeros(B), torch.zeros(B, D)
+        bt.item_rows = torch.zeros(B * L, D)
+        path.flat_g.zero_()
+        # the looked-up item rows: from this rank's replica, or ("sharded-table") from the owners of the rows
+        if replicate_table:
+            looked_up = path.tables["item"][ids.reshape(-1).long()].clone()
+        else:
+            ex.fetch_history_rows(bt)
+            looked_up = bt.item_rows.clone()
+        rows = looked_up.view(B, L, D).requires_grad_(True)
+        W = path.flat_p[:D * D].view(D, D).clone().requires_grad_(True)
+        live = (torch.arange(L)[None, :] < sl[:, None]).float()
+        pred = torch.tanh((rows * live[:, :, None]).sum(1) @ W)           # forward to pred
+        bt.pred = pred.detach().clone()
+        bt.ic = torch.cat([rows.detach().reshape(B * L, D), torch.zeros(B * L, D)], 1).contiguous()
+        ex.score(bt)
+        pred.backward(bt.d_pred)                                           # backward from d_pred
+        path.flat_g[:D * D] = W.grad.reshape(-1)
+        path.flat_g[small] = small_g[rank]
+        bt.d_ic = torch.cat([rows.grad.reshape(B * L, D), torch.zeros(B * L, D)], 1).contiguous()
+        bt.l2 = 0.5 * float((rows.detach() ** 2).sum())            # tf.nn.l2_loss: half the sum of squares
+        # the rank's own slots into its own rows, then the exchange applies the other ranks' slots
+        k.scatter_items(bt.d_ic, bt.ic, ids.reshape(-1), sl, B, L, path.reg, path.g_tab["item"], (ex.row_lo, ex.row_hi))
+        ex.exchange_and_apply(bt)
+        loss_err = max(loss_err, abs(float(bt.loss[0]) - float(loss_ref.detach())) / float(loss_ref.detach()))
+        ce_err = max(ce_err, err(bt.ce, ce_ref[rank * B:(rank + 1) * B].detach()))
 
     own = slice(ex.lo, ex.hi_true)
-    err = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    foreign_stale = 0.0
+    if not replicate_table:
+        # the rows this rank does not own were never refreshed: its replica differs from the reference there ...
+        mask = torch.ones(path.n_total, dtype=torch.bool)
+        mask[:off] = False
+        mask[own] = False
+        foreign_stale = float((path.flat_p[:path.n_total][mask] != ref.flat_p[:ref.n_total][mask]).float().mean())
+        assert not ex.table_current
+        ex.sync_item_table()        # ... until the replica is brought up to date (evaluation, checkpoints)
+        assert ex.table_current
     res = [err(path.flat_p[:path.n_total], ref.flat_p[:ref.n_total]), err(path.flat_m[own], ref.flat_m[own]),
            err(path.flat_v[own], ref.flat_v[own]), err(path.flat_m[:off], ref.flat_m[:off]),
-           abs(float(path.scale[1]) - float(ref.scale[1])) / float(ref.scale[1]),
-           abs(float(bt.loss[0]) - float(loss_ref.detach())) / float(loss_ref.detach()),
-           err(bt.ce, ce_ref[rank * B:(rank + 1) * B].detach()),
-           float(not bool(path.flat_p[path.n_total:].any())), float(path.refreshed)]
+           abs(float(path.scale[1]) - float(ref.scale[1])) / float(ref.scale[1]), loss_err, ce_err,
+           float(not bool(path.flat_p[path.n_total:].any())), float(path.refreshed), foreign_stale]
     np.save(os.path.join(out_dir, "scoring_%d.npy" % rank), np.array(res))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_sharded_scoring_exchange_equals_the_replicated_update(tmp_path, world):
+@pytest.mark.parametrize("replicate_table", [True, False])
+def test_sharded_scoring_exchange_equals_the_replicated_update(tmp_path, world, replicate_table):
     """Item table row-sharded for scoring: all-gather pred, every rank scores its own rows for the samples of every
     rank, the (max, sum-exp, target logit) triples and the d_pred shares are reduced, dE is born sharded, the other
     ranks' history slots are all-gathered and applied to the owned rows -- against ONE replica doing the whole batch
-    (autograd over the full-catalog softmax + L2, clip, dense Adam): parameters and both slots to fp32 rounding
-    (the sums run in a different order: per-rank partial log-sum-exps), the clip norm, the loss and the per-sample
-    cross entropies; 203 item rows over 2 and 4 ranks (pad rows untouched), the same in-place collectives as RCCL."""
-    port = 29500 + (os.getpid() % 2000) + 11 * world
-    mp.spawn(_scoring_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    (autograd over the full-catalog softmax + L2, clip, dense Adam), over TWO steps: parameters and both slots to fp32
+    rounding (the sums run in a different order: per-rank partial log-sum-exps), the clip norm, the loss and the
+    per-sample cross entropies; 203 item rows over 2 and 4 ranks (pad rows untouched), the same in-place collectives
+    as RCCL.  replicate_table=False ("sharded-table"): the updated rows are NOT all-gathered -- the second step's
+    lookups must get the rows the owners updated in the first (fetch_history_rows), the replicas' foreign rows are
+    measurably stale before sync_item_table() and equal to the reference after it."""
+    port = 29500 + (os.getpid() % 2000) + 11 * world + (3 if replicate_table else 0)
+    mp.spawn(_scoring_worker, args=(world, port, str(tmp_path), replicate_table, 2), nprocs=world, join=True)
     for rank in range(world):
-        p_err, m_err, v_err, ms_err, norm_err, loss_err, ce_err, pad_zero, refreshed = np.load(
+        p_err, m_err, v_err, ms_err, norm_err, loss_err, ce_err, pad_zero, refreshed, stale = np.load(
             os.path.join(str(tmp_path), "scoring_%d.npy" % rank))
-        assert p_err < 2e-6 and m_err < 2e-5 and v_err < 2e-5 and ms_err < 2e-5, (rank, p_err, m_err, v_err, ms_err)
+        assert p_err < 4e-6 and m_err < 4e-5 and v_err < 4e-5 and ms_err < 4e-5, (rank, p_err, m_err, v_err, ms_err)
         assert norm_err < 1e-6 and loss_err < 1e-6 and ce_err < 1e-5, (rank, norm_err, loss_err, ce_err)
-        assert pad_zero == 1.0 and refreshed == 1.0
+        assert pad_zero == 1.0 and refreshed == (2.0 if replicate_table else 3.0)
+        assert (stale == 0.0) if replicate_table else (stale > 0.9)

@@ -282,6 +282,24 @@ def test_emb_scatter_add_fused_sources(ops, B, L, with_user):
     assert abs(float(part.double().sum()) - float(part_ref.double().sum())) < 1e-5 * float(part_ref.double().sum())
 
 
+def test_rows_gather_range(ops):
+    """mtam_rows_gather_range: the rows of a ROW RANGE by catalog row number, zeros for rows outside it -- summed over
+    the ranges of a partition every id gets exactly its row (what the "sharded-table" reduce-scatter relies on)."""
+    rng = np.random.default_rng(9)
+    V, n = 1003, 777
+    E = dev(rng.standard_normal((V, D)).astype(np.float32))
+    ids = dev(rng.integers(0, V, n).astype(np.int32))
+    ids[0], ids[1] = 0, V - 1
+    total = torch.zeros((n, D), device="cuda")
+    for lo, hi in ((0, 126), (126, 630), (630, V)):
+        out = torch.full((n, D), 5.0, device="cuda")
+        ops.rows_gather_range(E[lo:hi], lo, ids, out)
+        owned = (ids >= lo) & (ids < hi)
+        assert torch.equal(out[owned], E[ids[owned].long()]) and not bool(out[~owned].any())
+        total += out
+    assert torch.equal(total, E[ids.long()])
+
+
 def test_emb_scatter_item_row_ranges(ops):
     """mtam_emb_scatter_add_bwd_range (data-parallel row-sharded scoring): with the item rows cut into ranges, the
     ranges' scatter-adds -- the owner's full call restricted to its rows, and the item-only form that applies ANOTHER

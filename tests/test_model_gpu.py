@@ -275,26 +275,29 @@ def test_sharded_item_exchange_single_rank(hip_lib, tmp_path, score_dtype):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("graph", [True, False])
-def test_sharded_scoring_exchange_single_rank(hip_lib, tmp_path, graph):
+@pytest.mark.parametrize("graph,exchange", [(True, "sharded-scoring"), (False, "sharded-scoring"), (True, "sharded-table"),
+                                            (False, "sharded-table")])
+def test_sharded_scoring_exchange_single_rank(hip_lib, tmp_path, graph, exchange):
     """data_parallel.ShardedScoringExchange (item table row-sharded for SCORING: all-gather pred, ranged lse /
-    backward passes, reduced (max, sum-exp, logit) and d_pred, slot exchange, shard-owned update, all-gather) through
+    backward passes, reduced (max, sum-exp, logit) and d_pred, slot exchange, shard-owned update, all-gather -- or,
+    "sharded-table", no all-gather and the lookups served from rows fetched from their owners) through
     the real kernels and a one-rank RCCL group -- forward-to-pred and backward-from-d_pred as two hipGraphs with the
     scoring passes and their collectives between them -- against the single-GPU step with the true clip norm."""
     import torch.distributed as dist
     from mtamrecommender_amd import data_parallel
     os_env = __import__("os").environ
     os_env.setdefault("MASTER_ADDR", "127.0.0.1")
-    os_env["MASTER_PORT"] = "29631" if graph else "29632"
+    os_env["MASTER_PORT"] = str(29631 + int(graph) + 2 * int(exchange == "sharded-table"))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         model_a, FLAGS, records = build(tmp_path, 32, 50, 1, 1, items=1000)
         model_b, _, _ = build(tmp_path, 32, 50, 1, 1, items=1000)
         model_a.path.tf_compat = False
         model_a.use_graph = model_b.use_graph = graph
-        data_parallel.attach(model_b.path, 1, force=True, exchange="sharded-scoring")
+        data_parallel.attach(model_b.path, 1, force=True, exchange=exchange)
         ex = model_b.path.sharded_scoring
-        assert ex is not None and (ex.row_lo, ex.row_hi) == (0, 1003) and model_b.path.dp_exchange == "sharded-scoring"
+        assert ex is not None and (ex.row_lo, ex.row_hi) == (0, 1003) and model_b.path.dp_exchange == exchange
+        assert ex.replicate_table == (exchange == "sharded-scoring")      # "sharded-table": lookups from fetched rows
         data_parallel.broadcast_parameters(model_b.path)
         for step in range(4):
             la, _ = model_a.train(model_a.sess, records, 1e-3)
@@ -308,6 +311,8 @@ def test_sharded_scoring_exchange_single_rank(hip_lib, tmp_path, graph):
             assert (np.abs(va[k] - vb[k]) > 2e-5).mean() < 2e-3, k
         for flat in (pb.flat_p, pb.flat_g, pb.flat_m, pb.flat_v):
             assert not bool(flat[pb.n_total:].any())
+        # evaluation brings a "sharded-table" replica up to date first (a collective inside metrics_topK)
+        assert model_b.recall_at(model_b.sess, records, 20) >= 0.0 and ex.table_current
     finally:
         dist.destroy_process_group()
 
