@@ -10,5 +10,6 @@ run c4 $B --items 10000000 --steps 20 --warmup 5
 export MTAM_BENCH_FORCE_DP=1
 run c4_dp1_sharded $B --items 10000000 --steps 20 --warmup 5 --dp-exchange sharded
 run c4_dp1_sharded_scoring $B --items 10000000 --steps 20 --warmup 5 --dp-exchange sharded-scoring
+run c4_dp1_sharded_table $B --items 10000000 --steps 20 --warmup 5 --dp-exchange sharded-table
 run c2_dp1_flat $B --steps 200 --warmup 20 --dp-exchange flat
 run c2_dp1_sharded_scoring $B --steps 200 --warmup 20 --dp-exchange sharded-scoring
