@@ -62,3 +62,19 @@ def test_world_size_mismatch_is_an_error():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-selftest"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode != 0 and b"WORLD_SIZE=3" in r.stderr
+
+
+def test_under_torch_distributed_run_the_file_is_one_rank():
+    """The driver may also start it as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`: WORLD_SIZE
+    is then set, no launcher runs, every process is one rank and rank 0 prints the line."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29713", BENCH, "--gpus", "2",
+                        "--launch-selftest", "--steps", "3", "--warmup", "1"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["ranks_seen"] == 2
+    assert b"launcher:" not in r.stderr
