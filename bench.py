@@ -252,8 +252,9 @@ def host_inclusive_rate(model, emb, records, steps, torch):
     elapsed = time.perf_counter() - t0
     model.async_loss = False
     return {"value": B_PER_GPU * steps / elapsed, "unit": "sequences/s", "ms_per_step": elapsed / steps * 1e3,
-            "steps": steps, "route": "RecordSet -> native packer thread -> pinned arena -> H2D -> model.train(), "
-                                     "loss returned one step late (async_loss)"}
+            "steps": steps, "route": "RecordSet -> native packer thread -> pinned arena -> model.train(): ONE hipGraph "
+                                     "launch per step (the arena's H2D copy is its first node, the loss's D2H copy its "
+                                     "last; loss returned one step late, async_loss)"}
 
 
 def cpu_baseline(records_batches, FLAGS, arrays, budget_s=15.0, model_name="MTAM"):
@@ -600,6 +601,8 @@ def main():
                      "traffic": pmc_step_traffic("seq_chain_x3_kernel") if x3 and (L, B_PER_GPU) == (50, 128) else None,
                      "flops_per_launch": flops, "us_per_launch": t_fused * 1e6,
                      "lookup_bytes_per_launch_fused_bound": lookup_bytes,
+                     "what_bounds_it": "not the matrix pipe: every workgroup pulls all of the weights' images from L2 "
+                                       "(~70 GB/s per CU) beside 22.9 MB of stores and the gather (DESIGN.md 5.0)",
                      "kv_projection": "inside this launch" if kv_here else
                                       "extra workgroups of the GRU launch (the CUs the recurrence leaves idle)",
                      "note": "the training step's embedding lookups run inside this kernel; the stand-alone gather "
@@ -631,8 +634,10 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.score_dtype == "f32" else "bf16 scoring operands, f32 accumulate and elsewhere",
             "arith": ("training GEMMs and catalog scoring: fp32 via 3 x bf16 split operands (6 bf16-MFMA terms per "
                       "product, each exact), fp32 accumulate -- fp32-equivalent (tested to fp64 within 2x a native "
-                      "fp32 matmul's error); fused forward projections: native fp32 MFMA; GRU / attention / "
-                      "optimizer / lookups: fp32 VALU; evaluation scores: k-ordered fp32 fmaf chain"),
+                      "fp32 matmul's error), the fused forward projections, the backward stripe kernel and the K/V "
+                      "riders of the GRU launches included (weights pre-split into bf16 operand images by the Adam "
+                      "launch); GRU / attention / optimizer / lookups: fp32 VALU; evaluation scores: k-ordered fp32 "
+                      "fmaf chain"),
             "data": "synthetic", "ranks_seen": ranks_seen, "ms_per_step_by_rank": per_rank_ms,
             "rehearsal": ("every rank on cuda:0, gloo collectives (MTAM_BENCH_SHARE_GPU=1): NOT a measurement"
                           if share_gpu else None),
