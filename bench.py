@@ -431,6 +431,9 @@ def main():
     share_gpu = os.environ.get("MTAM_BENCH_SHARE_GPU", "0") == "1"
     if share_gpu:
         local_rank = 0
+        # the one-launch scoring kernel waits inside the launch for all of its workgroups to be resident: grids of
+        # several processes on ONE device could wait on each other's CUs (csrc/score32.hip, small_form)
+        os.environ["MTAM_SCORE32_FUSED"] = "0"
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     # MTAM_BENCH_FORCE_DP=1: run the multi-GPU code path (RCCL group, gradient exchange, barriers, max over

@@ -497,6 +497,23 @@ int mtam_score32_bwd_range(const float *E, const float *pred, const float *lse, 
                            int row0, float scale, float *d_pred, float *dE, float *sq_partial, int n_sq_partial,
                            void *stream);
 
+/* Training's scoring as ONE call (Model/base_model.py:309-328, the loss, and 290-297, its two scoring gradients):
+ * ce[b] = lse[b] - logit of the target, d_pred += G E, dE = G^T pred (stored) with G = (softmax - onehot) * scale.
+ * With one batch tile (B <= 128) and 8 <= ceil(V / 32) <= 168 (and 7/8 of the device's CU count; 3,709 rows: 116 slabs) this is ONE
+ * launch: every 32-row slab has a resident workgroup of its own, the scores stay in registers across a grid barrier,
+ * the per-slab shares of d_pred are summed in slab order (deterministic; no float atomics), against
+ * 6.3 + 4.7 + 15.8 us for the three launches of lse + bwd.  mtam_score32_train_is_fused() says whether that form
+ * applies (MTAM_SCORE32_FUSED=0 turns it off -- required when several processes share one GPU); otherwise the call is
+ * mtam_score32_lse followed by mtam_score32_bwd.  `work`: mtam_score32_train_work_floats(B, V) floats, 16-byte aligned,
+ * prepared ONCE by mtam_score32_train_work_init (the fused form's exchange buffers must start as "nothing published")
+ * and then left to mtam_score32_train; one buffer serves one (B, V) and one stream. */
+int mtam_score32_train_is_fused(int B, int V);
+long mtam_score32_train_work_floats(int B, int V);
+int mtam_score32_train_work_init(float *work, long n_work, int B, int V, void *stream);
+int mtam_score32_train(const float *E, const float *pred, const int32_t *target, int B, int V, float scale,
+                       float *work, long n_work, float *lse, float *ce, float *d_pred, float *dE, float *sq_partial,
+                       int n_sq_partial, void *stream);
+
 /* ------------------------------------------- the forward's three sequence-side projections in one launch
  *   zr = relu(ic W4) ; x = zr + pos                       (Embedding/...attention.py:95-103; = mtam_gemm_f32 RELU_ADD)
  *   kv = relu(x Wkv + bkv)  [R, n_kv]   (n_kv may be 0)    (time_aware_attention.py:251-253;   = BIAS_RELU)

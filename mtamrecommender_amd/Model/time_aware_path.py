@@ -406,14 +406,30 @@ class TimeAwarePath(object):
         self.refresh_item16()
         self.refresh_weight_images()
 
+    def _score_fused_on(self, bt):
+        """Training's two scoring passes as ONE launch (csrc/score32.hip, x3::train_small_kernel): when the step runs
+        forward and backward back to back (``bt.train_step``: nothing reads the loss terms in between) and the catalog
+        is small enough for every slab to have a resident workgroup.  The cross entropies then come out of the
+        BACKWARD's first launch."""
+        if not (self.logits_free32 and getattr(bt, "train_step", False) and self.sharded_scoring is None):
+            return False
+        if getattr(bt, "s32_work", None) is None:
+            if not ops.score32_train_is_fused(bt.B, self.item_rows):
+                bt.s32_work = False
+            else:
+                bt.s32_work = ops.score32_train_work(bt.B, self.item_rows, self.device)
+        return bt.s32_work is not False
+
     # ----------------------------------------------------------------- scoring (base_model.output)
     def score_forward(self, bt, training):
         """logits = pred . E^T (Model/base_model.py:309-312).  bf16 training keeps no logits: it goes
         straight to lse / cross entropy."""
         V = self.item_rows
         if self.logits_free32 and training:
-            ops.score32_lse(self.tables["item"], bt.pred, bt.feed["target_item_id"], bt.B, V, bt.s32_partial,
-                            bt.lse, bt.ce)
+            bt.score_in_backward = self._score_fused_on(bt)
+            if not bt.score_in_backward:
+                ops.score32_lse(self.tables["item"], bt.pred, bt.feed["target_item_id"], bt.B, V, bt.s32_partial,
+                                bt.lse, bt.ce)
             return
         if self.score_dtype == "f32":
             ops.gemm(bt.pred, self.tables["item"], bt.logits_store, trans_b=True, split=False)
@@ -428,6 +444,11 @@ class TimeAwarePath(object):
         """dE (every row; its share of the TF global norm on the way out) and d_pred (accumulated)."""
         part, V = bt.norm_partial, self.item_rows
         sq = part[self.nb_dense:] if self.tf_compat else None
+        if self.logits_free32 and getattr(bt, "score_in_backward", False):
+            # small catalogs: the log-sum-exp pass, the loss terms and both gradients as ONE launch
+            ops.score32_train(self.tables["item"], bt.pred, bt.feed["target_item_id"], bt.B, V, 1.0 / self.gb(bt),
+                              bt.s32_work, bt.lse, bt.ce, bt.d_pred, self.g_tab["item"], sq, n_sq=self.nb_item)
+            return
         if self.logits_free32:
             ops.score32_bwd(self.tables["item"], bt.pred, bt.lse, bt.feed["target_item_id"], bt.B, V,
                             1.0 / self.gb(bt), bt.d_pred, self.g_tab["item"], sq, n_sq=self.nb_item)
@@ -725,7 +746,11 @@ class TimeAwarePath(object):
         self.refresh_derived()
 
     def forward_backward_kernels(self, bt):
-        self.forward(bt, training=True)
+        bt.train_step = True             # forward and backward back to back: the scoring passes may merge
+        try:
+            self.forward(bt, training=True)
+        finally:
+            bt.train_step = False
         self.loss_and_logit_grad(bt)
         self.backward(bt)
 

@@ -58,6 +58,16 @@ __device__ unsigned long long g_score_wg[2][4096][3];       // [kernel][workgrou
 #define SC_STAMP_DUMP(k)
 #endif
 
+// tools/score_small_lab.hip (-DMTAM_SMALL_STAMPS): s_memrealtime (100 MHz) at the phase boundaries of the one-launch
+// small-catalog kernel, first wave of each role of the middle workgroup
+#ifdef MTAM_SMALL_STAMPS
+__device__ unsigned long long g_small_stamps[3][16];
+#define SM_STAMP(i)                                                                      \
+  if (lane == 0 && w == 0 && c == G / 2) g_small_stamps[role][i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define SM_STAMP(i)
+#endif
+
 namespace {
 
 constexpr int D = MTAM_D;
@@ -727,6 +737,417 @@ __global__ __launch_bounds__(768) void bwd_tr3_kernel(BwdArgs p) {
   }
 }
 
+
+// ---- small catalogs: the whole of training's scoring -- log-sum-exp, loss, G, d_pred, dE -- in ONE launch.
+// At 3,709 rows the three launches above (lse 6.3 us, finish 4.7, backward 15.8) are chains of short phases on 116 of
+// the 256 CUs: two launch gaps, the slab staged, split and multiplied twice, and 116 x 64 KB of float atomics for d_pred.
+// When every slab can have its own RESIDENT workgroup (slabs <= CUs, one batch tile) the scores stay in the S waves'
+// accumulators while the workgroups exchange what the softmax needs INSIDE the launch:
+//     S waves   scores of the slab -> (max, sum-exp) of the slab per sample, published -> every workgroup folds the
+//               G x 128 pairs itself (lse; the lane holding the target's score writes the cross entropy) -> G -> G^T image
+//     D waves   the slab's share of d_pred, published to a [G][128][128] scratch (stores, no atomics) -> every workgroup
+//               sums its 1/G of d_pred over the G shares in a fixed order (deterministic, unlike the atomics)
+//     T waves   dE rows of the slab and their squares, as in bwd_tr3_kernel
+// "Published": write-through (sc1) stores, read by sc1 loads (16-byte ones, by inline asm: the atomic builtins stop at
+// 8 bytes).  There is no barrier object: the DATA is its own flag.  Both exchange buffers exist twice; a launch works in
+// the copy of its epoch's parity and refills the OTHER copy with a sentinel (all-ones words, which no sum-exp and no
+// finite product is), so a reader polls the very words it needs until none of them is the sentinel: every dependent
+// step is one trip to memory (~1.4 us here), not store -> flag -> poll -> load.  Two earlier forms, measured with
+// tools/score_small_lab.hip at 116 workgroups: arrival counter + generation word, 45 ns per workgroup on the
+// same-address atomics, 6.1 + 4.3 us in barriers of a 26 us launch; one flag per workgroup polled by four waves,
+// 3.0 + 2.8 us in barriers, 23.7 us.  A reader gives up after ~1 s of polling (it cannot hang the device); the launch
+// then writes NaN.
+constexpr int SMALL_MS_PARTS = 12;                      // 768 threads = 12 x 64 sample pairs
+constexpr int SMALL_D_SCRATCH = 4 * 32 * T_PITCH * 4;   // the D waves' way out (as the T waves' t_scratch)
+constexpr int SMALL_LDS = 3 * E2_IMG + 3 * GT2_IMG + OUT_SCRATCH + SMALL_D_SCRATCH + SMALL_MS_PARTS * BT * 8;
+constexpr long SMALL_SPIN_LIMIT = 1L << 19;
+constexpr int SMALL_MAX_G = 12 * 14;                    // one batch of 14 loads per thread folds the pairs: 5,376 rows
+constexpr int SMALL_HEAD_WORDS = 64;                    // [0] epoch (launches so far on this buffer)
+constexpr unsigned int SMALL_SENTINEL = 0xffffffffu;
+
+struct SmallArgs {
+  const float *E, *P;
+  const int32_t *target;
+  int V, Bt;
+  float scale;
+  unsigned int *head;          // SMALL_HEAD_WORDS words
+  float *ms;                   // [2][G][128] (max, sum-exp) pairs
+  float *dp_part;              // [2][G][128][128] shares of d_pred
+  float *lse, *ce, *d_pred, *dE, *sq_partial;
+};
+
+// (a VMEM store of more than 8 bytes must not be followed at once by a VALU write of its data registers: the
+// assembler's hazard pass does not see inside inline asm, hence the s_nop)
+__device__ __forceinline__ void store16_sc1(float *p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+// N 16-byte sc1 loads in flight, then the wait (the compiler does not count loads issued by inline asm)
+__device__ __forceinline__ void load16x8_sc1(f32x4 (&v)[8], const float *const (&src)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\t"
+      "global_load_dwordx4 %1, %9, off sc1\n\t"
+      "global_load_dwordx4 %2, %10, off sc1\n\t"
+      "global_load_dwordx4 %3, %11, off sc1\n\t"
+      "global_load_dwordx4 %4, %12, off sc1\n\t"
+      "global_load_dwordx4 %5, %13, off sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc1\n\t"
+      "global_load_dwordx4 %7, %15, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7])
+      : "memory");
+}
+// (base in SGPRs + a 32-bit byte offset per load: 14 + 14 + 1 operands)
+__device__ __forceinline__ void load16x14_sc1(f32x4 (&v)[14], const float *base, const unsigned int (&off)[14]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %14, %28 sc1\n\t"
+      "global_load_dwordx4 %1, %15, %28 sc1\n\t"
+      "global_load_dwordx4 %2, %16, %28 sc1\n\t"
+      "global_load_dwordx4 %3, %17, %28 sc1\n\t"
+      "global_load_dwordx4 %4, %18, %28 sc1\n\t"
+      "global_load_dwordx4 %5, %19, %28 sc1\n\t"
+      "global_load_dwordx4 %6, %20, %28 sc1\n\t"
+      "global_load_dwordx4 %7, %21, %28 sc1\n\t"
+      "global_load_dwordx4 %8, %22, %28 sc1\n\t"
+      "global_load_dwordx4 %9, %23, %28 sc1\n\t"
+      "global_load_dwordx4 %10, %24, %28 sc1\n\t"
+      "global_load_dwordx4 %11, %25, %28 sc1\n\t"
+      "global_load_dwordx4 %12, %26, %28 sc1\n\t"
+      "global_load_dwordx4 %13, %27, %28 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+        "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13])
+      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]),
+        "v"(off[8]), "v"(off[9]), "v"(off[10]), "v"(off[11]), "v"(off[12]), "v"(off[13]), "s"(base)
+      : "memory");
+}
+__device__ __forceinline__ bool is_sentinel(float x) { return __float_as_uint(x) == SMALL_SENTINEL; }
+
+// Every thread: fold the G (max, sum-exp) pairs of every sample -- 12 threads per PAIR of samples, each polling its own
+// <= 14 pieces of 16 bytes until all of them have been published -- into LDS.
+__device__ __forceinline__ void small_fold_pairs(const float *ms, int G, int tid, float2 *ms_lds) {
+  const int bp = tid & 63, part = tid >> 6;
+  f32x4 v[14];
+  unsigned int off[14];       // bytes
+#pragma unroll
+  for (int j = 0; j < 14; ++j) off[j] = ((unsigned int)min(part + SMALL_MS_PARTS * j, G - 1) * BT + 2 * bp) * 8u;
+  bool good = true;
+  for (long spins = 0;; ++spins) {
+    load16x14_sc1(v, ms, off);
+    bool miss = false;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) miss = miss || is_sentinel(v[j][1]) || is_sentinel(v[j][3]);
+    if (__builtin_amdgcn_ballot_w64(miss) == 0) break;
+    if (spins > SMALL_SPIN_LIMIT) { good = false; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  float M0 = -INFINITY, S0 = 0.f, M1 = -INFINITY, S1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 14; ++j) {
+    if (part + SMALL_MS_PARTS * j < G) {
+      float Mn = fmaxf(M0, v[j][0]);
+      S0 = S0 * fast_exp2((M0 - Mn) * L2E) + v[j][1] * fast_exp2((v[j][0] - Mn) * L2E);
+      M0 = Mn;
+      Mn = fmaxf(M1, v[j][2]);
+      S1 = S1 * fast_exp2((M1 - Mn) * L2E) + v[j][3] * fast_exp2((v[j][2] - Mn) * L2E);
+      M1 = Mn;
+    }
+  }
+  if (!good) S0 = S1 = __builtin_nanf("");
+  *reinterpret_cast<f32x4 *>(&ms_lds[part * BT + 2 * bp]) = f32x4{M0, S0, M1, S1};
+}
+
+// Every thread: this workgroup's 1/G of d_pred, summed over the G shares in a fixed order; a thread polls its own
+// pieces of the shares until all of them have been published.
+__device__ __forceinline__ void small_reduce_d_pred(const SmallArgs &p, const float *dp_part, int G, int c, int tid,
+                                                    f32x4 *red) {
+  const int units = p.Bt * (D / 4);                 // 16-byte pieces of d_pred
+  const int U = (units + G - 1) / G;                // <= 512 (G >= 8)
+  const int groups = min(768 / U, G);
+  const int ul = tid % U, grp = tid / U;
+  const int unit = c * U + ul;
+  if (grp < groups) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    const int uc = min(unit, units - 1);
+    for (int g0 = grp; g0 < G; g0 += groups * 8) {
+      f32x4 v[8];
+      const float *src[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) src[j] = dp_part + (size_t)min(g0 + groups * j, G - 1) * BT * D + 4 * (size_t)uc;
+      bool good = true;
+      for (long spins = 0;; ++spins) {
+        load16x8_sc1(v, src);
+        bool miss = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          miss = miss || is_sentinel(v[j][0]) || is_sentinel(v[j][1]) || is_sentinel(v[j][2]) || is_sentinel(v[j][3]);
+        if (!miss) break;
+        if (spins > SMALL_SPIN_LIMIT) { good = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (g0 + groups * j < G) a += v[j];
+      if (!good) a[0] = __builtin_nanf("");
+    }
+    red[grp * U + ul] = a;
+  }
+  __syncthreads();
+  if (grp == 0 && unit < units) {
+    f32x4 t = red[ul];
+    for (int k = 1; k < groups; ++k) t += red[k * U + ul];
+    f32x4 *const dst = reinterpret_cast<f32x4 *>(p.d_pred) + unit;
+    *dst = *dst + t;
+  }
+}
+
+// The three roles run the same sequence of workgroup barriers: [slab staged] [scored] fold [pairs in LDS] [G^T image]
+// products [products done] reduce (one barrier inside).
+__global__ __launch_bounds__(768) void train_small_kernel(SmallArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char *const e_img = lds;                                   // [3][E2_IMG]
+  unsigned char *const gt_img = lds + 3 * E2_IMG;                     // [3][GT2_IMG]
+  float *const t_scratch = reinterpret_cast<float *>(gt_img + 3 * GT2_IMG);
+  float *const d_scratch = t_scratch + OUT_SCRATCH / 4;
+  float2 *const ms_lds = reinterpret_cast<float2 *>(d_scratch + SMALL_D_SCRATCH / 4);      // [12][128] (max, sum-exp)
+  f32x4 *const red = reinterpret_cast<f32x4 *>(e_img);                // the reduction: [groups][U], <= 12 KB of 24
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int role = wave >> 2, w = wave & 3;
+  const int V = p.V, G = gridDim.x, c = blockIdx.x;
+  const int vbase = c * SLAB;
+  const int cg = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;      // transposed-read lane roles
+  const int dcol = 32 * w + r;
+  // this launch's copies of the exchange buffers, and the copies to refill with the sentinel for the next one
+  const unsigned int epoch = p.head[0];
+  const size_t ms_copy = (size_t)G * BT * 2, dp_copy = (size_t)G * BT * D;
+  float *const ms = p.ms + (epoch & 1) * ms_copy, *const ms_next = p.ms + ((epoch & 1) ^ 1) * ms_copy;
+  float *const dp_part = p.dp_part + (epoch & 1) * dp_copy, *const dp_next = p.dp_part + ((epoch & 1) ^ 1) * dp_copy;
+  const f32x4 sentinel4 = {__uint_as_float(SMALL_SENTINEL), __uint_as_float(SMALL_SENTINEL),
+                           __uint_as_float(SMALL_SENTINEL), __uint_as_float(SMALL_SENTINEL)};
+  SM_STAMP(0)
+
+  if (role == 0) {
+    // ------------------------------------------------------------------ S waves (batch rows 32 w ..)
+    const int bcol = 32 * w + r;
+    const bool valid_b = bcol < p.Bt;
+    const int brow = min(bcol, p.Bt - 1);
+    Stage st;
+    stage_load(st, p.E, vbase, V, tid);
+    Tri p1[8];
+    load_pred_rows(p1, p.P + (size_t)brow * D, h);
+    const int t_rel = local_target(p.target[brow], -1, V) - vbase - 4 * h;
+    stage_store_split_tr(st, e_img, tid);
+    __syncthreads();                               // [slab staged]
+    SM_STAMP(1)
+    f32x16 acc = {0.f};
+    const int swz_r = ((r & 3) << 2) | ((r >> 2) & 3);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      Tri a;
+      const int o = 256 * r + 16 * ((2 * s + h) ^ swz_r);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) a.t[t] = *reinterpret_cast<const bf16x8 *>(e_img + t * E2_IMG + o);
+      acc = mfma6(a, p1[s], acc);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const bool in = vbase + 4 * h + (q & 3) + 8 * (q >> 2) < V;
+      m = fmaxf(m, in ? acc[q] : -INFINITY);
+    }
+    const float nref = -((m == -INFINITY) ? 0.f : m) * L2E;
+    float ssum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const bool in = vbase + 4 * h + (q & 3) + 8 * (q >> 2) < V;
+      ssum += in ? fast_exp2(fmaf(acc[q], L2E, nref)) : 0.f;
+    }
+    const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(ssum, 32, 64);
+    const float mm = fmaxf(m, m2), rf = (mm == -INFINITY) ? 0.f : mm;
+    const float ss = ssum * fast_exp2((m - rf) * L2E) + s2 * fast_exp2((m2 - rf) * L2E);
+    if (h == 0) {                                  // one 8-byte write-through store: the pair appears whole
+      const unsigned long long pair = (unsigned long long)__float_as_uint(mm) |
+                                      ((unsigned long long)__float_as_uint(ss) << 32);
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(ms) + (size_t)c * BT + bcol, pair, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    SM_STAMP(2)
+    __syncthreads();                               // [scored] (nobody polls before this workgroup has published)
+    small_fold_pairs(ms, G, tid, ms_lds);
+    __syncthreads();                               // [pairs in LDS]
+    SM_STAMP(4)
+    float M = -INFINITY, S = 0.f;
+#pragma unroll
+    for (int k = 0; k < SMALL_MS_PARTS; ++k) {
+      const float2 q = ms_lds[k * BT + bcol];
+      const float Mn = fmaxf(M, q.x);
+      if (Mn != -INFINITY) S = S * fast_exp2((M - Mn) * L2E) + q.y * fast_exp2((q.x - Mn) * L2E);
+      M = Mn;
+    }
+    const float lse = M + logf(S);
+    if (c == 0 && h == 0 && valid_b) p.lse[bcol] = lse;
+    const float c_b = valid_b ? fmaf(-lse, L2E, log2f(p.scale)) : -INFINITY;
+    float g[16];
+    float tl = 0.f;
+    bool has = false;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = (q & 3) + 8 * (q >> 2);
+      g[q] = fast_exp2(fmaf(acc[q], L2E, c_b));
+      if (row == t_rel) {
+        tl = acc[q];
+        has = true;
+        g[q] -= valid_b ? p.scale : 0.f;
+      }
+      g[q] = (vbase + row + 4 * h < V) ? g[q] : 0.f;
+    }
+    if (has && valid_b) p.ce[bcol] = lse - tl;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      bf16x4 gq[3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        __bf16 a, b, cc;
+        split3(g[4 * q4 + k], a, b, cc);
+        gq[0][k] = a; gq[1][k] = b; gq[2][k] = cc;
+      }
+      const int o = gt_off(bcol, q4) + 8 * h;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4 *>(gt_img + t * GT2_IMG + o) = gq[t];
+    }
+    __syncthreads();                               // [G^T image]
+    SM_STAMP(5)
+    // refill the other copy of this workgroup's pairs for the next launch (plain stores: a launch boundary lies between)
+    if (tid < BT / 2) *reinterpret_cast<f32x4 *>(ms_next + ((size_t)c * BT + 2 * tid) * 2) = sentinel4;
+    __syncthreads();                               // [products done]
+    small_reduce_d_pred(p, dp_part, G, c, tid, red);
+    SM_STAMP(8)
+    // (every workgroup has read the epoch before it published its pairs, and this one has seen all of them)
+    if (c == 0 && tid == 0) p.head[0] = epoch + 1;
+    return;
+  }
+
+  if (role == 1) {
+    // ------------------------------------------------------------------ D waves: the slab's share of d_pred
+    int et_off[2], ga_off[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) et_off[jj] = e_off(8 * h + 4 * jj + tq, 4 * w + 2 * cg + (tp >> 1)) + 8 * (tp & 1);
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) ga_off[sp] = gt_off(r, 2 * sp + h);
+    __syncthreads();                               // [slab staged]
+    __syncthreads();                               // [scored]
+    small_fold_pairs(ms, G, tid, ms_lds);
+    __syncthreads();                               // [pairs in LDS]
+    __syncthreads();                               // [G^T image]
+    SM_STAMP(5)
+    f32x16 dp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dp[i] = f32x16{0.f};
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      Tri bf;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        bf.t[t] = lds_tr8(e_img + t * E2_IMG + 4096 * sp + et_off[0], e_img + t * E2_IMG + 4096 * sp + et_off[1]);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        Tri a;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          a.t[t] = *reinterpret_cast<const bf16x8 *>(gt_img + t * GT2_IMG + 2048 * mb + ga_off[sp]);
+        dp[mb] = mfma6(a, bf, dp[mb]);
+      }
+    }
+    SM_STAMP(9)
+    // out through a wave-private scratch: 32 rows x 32 columns become four 16-byte write-through stores per lane
+    float *const sc = d_scratch + w * (32 * T_PITCH);
+    float *const out = dp_part + (size_t)c * BT * D + 32 * w;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sc[acc_row(q, h) * T_PITCH + r] = dp[mb][q];
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const int idx = i4 * 64 + lane, row = idx >> 3, c4 = idx & 7;
+        store16_sc1(out + (size_t)(32 * mb + row) * D + 4 * c4, *reinterpret_cast<const f32x4 *>(sc + row * T_PITCH + 4 * c4));
+      }
+    }
+    SM_STAMP(6)
+    __syncthreads();                               // [products done]
+    small_reduce_d_pred(p, dp_part, G, c, tid, red);
+    SM_STAMP(8)
+    // off the chain: refill the other copy of this workgroup's share for the next launch (plain stores: a launch
+    // boundary lies between)
+    {
+      f32x4 *const dst = reinterpret_cast<f32x4 *>(dp_next + (size_t)c * BT * D);
+#pragma unroll
+      for (int i = 0; i < BT * D / 4 / 256; ++i) dst[i * 256 + (tid - 256)] = sentinel4;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- T waves: dE (columns d = 32 w ..)
+  Tri p2[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = p.P[(size_t)min(16 * s + 8 * h + j, p.Bt - 1) * D + dcol];
+    p2[s] = split8(x);
+  }
+  int gt_rd[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) gt_rd[jj] = gt_off(8 * h + 4 * jj + tq, 2 * cg + (tp >> 1)) + 8 * (tp & 1);
+  __syncthreads();                                 // [slab staged]
+  __syncthreads();                                 // [scored]
+  small_fold_pairs(ms, G, tid, ms_lds);
+  __syncthreads();                                 // [pairs in LDS]
+  __syncthreads();                                 // [G^T image]
+  SM_STAMP(5)
+  f32x16 de = {0.f};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    Tri a;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      a.t[t] = lds_tr8(gt_img + t * GT2_IMG + 1024 * s + gt_rd[0], gt_img + t * GT2_IMG + 1024 * s + gt_rd[1]);
+    de = mfma6(a, p2[s], de);
+  }
+  float sq = 0.f;
+  if (vbase + SLAB <= V) {           // through a wave-private scratch: four 16-byte stores per lane
+    float *const sc = t_scratch + w * (32 * T_PITCH);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      sq = fmaf(de[q], de[q], sq);
+      sc[((q & 3) + 8 * (q >> 2) + 4 * h) * T_PITCH + r] = de[q];
+    }
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int idx = i4 * 64 + lane, row = idx >> 3, c4 = idx & 7;
+      const f32x4 t = *reinterpret_cast<const f32x4 *>(sc + row * T_PITCH + 4 * c4);
+      *reinterpret_cast<f32x4 *>(p.dE + ((size_t)vbase + row) * D + 32 * w + 4 * c4) = t;
+    }
+  } else {
+    float *const out = p.dE + ((size_t)vbase + 4 * h) * D + dcol;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = (q & 3) + 8 * (q >> 2);
+      if (vbase + row + 4 * h < V) {
+        sq = fmaf(de[q], de[q], sq);
+        out[(size_t)row * D] = de[q];
+      }
+    }
+  }
+  if (p.sq_partial) {
+    sq = wave_sum(sq);
+    if (lane == 0) p.sq_partial[(size_t)c * 4 + w] = sq;
+  }
+  SM_STAMP(6)
+  __syncthreads();                                 // [products done]
+  small_reduce_d_pred(p, dp_part, G, c, tid, red);
+  SM_STAMP(8)
+}
+
 }  // namespace x3
 
 
@@ -851,5 +1272,84 @@ extern "C" int mtam_score32_bwd_range(const float *E, const float *pred, const f
       hipLaunchKernelGGL(score32_bwd_kernel<true>, dim3(grid_of(V)), dim3(256), 0, st, a);
   }
   MTAM_CHECK_LAUNCH("score32_bwd");
+  return MTAM_OK;
+}
+
+// ---- training's scoring as ONE call: per-sample loss terms and both scoring gradients.
+namespace {
+int cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return v;
+  }();
+  return n;
+}
+// the one-launch form (x3::train_small_kernel): one batch tile, every slab a resident workgroup of its own
+// (MTAM_SCORE32_FUSED=0 turns it off; processes SHARING a GPU must turn it off -- their grids would wait on each
+// other's CUs)
+bool small_form(int B, int V) {
+  static const bool on = [] {
+    const char *e = getenv("MTAM_SCORE32_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  const int G = slabs_of(V);
+  return on && use_split(V) && B <= BT && G >= 8 && G <= min(cu_count() / 8 * 7, x3::SMALL_MAX_G);      // (CUs to spare)
+}
+}  // namespace
+
+extern "C" int mtam_score32_train_is_fused(int B, int V) { return (B > 0 && V > 0 && small_form(B, V)) ? 1 : 0; }
+
+extern "C" long mtam_score32_train_work_floats(int B, int V) {
+  if (B <= 0 || V <= 0) return 0;
+  if (small_form(B, V)) return x3::SMALL_HEAD_WORDS + 2 * ((long)slabs_of(V) * BT * 2 + (long)slabs_of(V) * BT * D);
+  return mtam_score32_partials(B, V);
+}
+
+extern "C" int mtam_score32_train_work_init(float *work, long n_work, int B, int V, void *stream) {
+  MTAM_CHECK_ARG(work && B > 0 && V > 0 && n_work >= mtam_score32_train_work_floats(B, V),
+                 "score32_train_work_init: work holds %ld floats, B=%d V=%d needs %ld", n_work, B, V,
+                 mtam_score32_train_work_floats(B, V));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(work, 0, (size_t)n_work * 4, s);
+  if (e == hipSuccess && small_form(B, V))       // the exchange buffers start as "nothing published"
+    e = hipMemsetAsync(work + x3::SMALL_HEAD_WORDS, 0xff, (size_t)(n_work - x3::SMALL_HEAD_WORDS) * 4, s);
+  MTAM_CHECK_ARG(e == hipSuccess, "score32_train_work_init: %s", hipGetErrorString(e));
+  return MTAM_OK;
+}
+
+extern "C" int mtam_score32_train(const float *E, const float *pred, const int32_t *target, int B, int V, float scale,
+                                  float *work, long n_work, float *lse, float *ce, float *d_pred, float *dE,
+                                  float *sq_partial, int n_sq_partial, void *stream) {
+  MTAM_CHECK_ARG(E && pred && target && work && lse && ce && d_pred && dE, "score32_train: null argument");
+  MTAM_CHECK_ARG(B > 0 && V > 0 && V < 0x7fffff00 && scale > 0.f, "score32_train: bad shape B=%d V=%d", B, V);
+  MTAM_CHECK_ARG(n_work >= mtam_score32_train_work_floats(B, V),
+                 "score32_train: work holds %ld floats, this form needs %ld", n_work,
+                 mtam_score32_train_work_floats(B, V));
+  if (!small_form(B, V)) {
+    const int rc = mtam_score32_lse(E, pred, target, B, V, work, (int)min(n_work, (long)0x7fffffff), lse, ce, stream);
+    if (rc != MTAM_OK) return rc;
+    return mtam_score32_bwd(E, pred, lse, target, B, V, scale, d_pred, dE, sq_partial, n_sq_partial, stream);
+  }
+  MTAM_CHECK_ARG(!sq_partial || n_sq_partial == mtam_score32_sq_partials(V),
+                 "score32_train: sq_partial holds %d floats, this form of the pass writes %d", n_sq_partial,
+                 mtam_score32_sq_partials(V));
+  MTAM_CHECK_ARG(mtam_aligned16(E) && mtam_aligned16(pred) && mtam_aligned16(work) && mtam_aligned16(d_pred) &&
+                 mtam_aligned16(dE), "score32_train: operands must be 16-byte aligned");
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(x3::train_small_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, x3::SMALL_LDS);
+    MTAM_CHECK_ARG(e == hipSuccess, "score32_train: cannot reserve %d bytes of LDS: %s", x3::SMALL_LDS,
+                   hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int G = slabs_of(V);
+  x3::SmallArgs a{E, pred, target, V, B, scale,
+                  reinterpret_cast<unsigned int *>(work), work + x3::SMALL_HEAD_WORDS,
+                  work + x3::SMALL_HEAD_WORDS + 2 * (long)G * BT * 2, lse, ce, d_pred, dE, sq_partial};
+  hipLaunchKernelGGL(x3::train_small_kernel, dim3(G), dim3(768), x3::SMALL_LDS, static_cast<hipStream_t>(stream), a);
+  MTAM_CHECK_LAUNCH("score32_train");
   return MTAM_OK;
 }

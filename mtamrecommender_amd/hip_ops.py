@@ -530,6 +530,33 @@ def score32_bwd(E, pred, lse, target, B, V, scale, d_pred, dE, sq_partial=None, 
                "mtam_score32_bwd")
 
 
+def score32_train_is_fused(B, V):
+    """Whether score32_train runs as ONE launch at this size (csrc/score32.hip, x3::train_small_kernel)."""
+    return bool(_lib.load().mtam_score32_train_is_fused(int(B), int(V)))
+
+
+def score32_train_work_floats(B, V):
+    return int(_lib.load().mtam_score32_train_work_floats(int(B), int(V)))
+
+
+def score32_train_work(B, V, device="cuda"):
+    """The work buffer of score32_train for this (B, V), prepared (mtam_score32_train_work_init)."""
+    work = torch.empty(score32_train_work_floats(B, V), dtype=torch.float32, device=device)
+    _lib.check(_lib.load().mtam_score32_train_work_init(_p(work), work.numel(), int(B), int(V), _stream()),
+               "mtam_score32_train_work_init")
+    return work
+
+
+def score32_train(E, pred, target, B, V, scale, work, lse, ce, d_pred, dE, sq_partial=None, n_sq=None):
+    """Training's scoring in one call: ce = lse - target logit, d_pred += G E, dE = G^T pred.  ``work``:
+    score32_train_work(B, V), then left to this call."""
+    lib = _lib.load()
+    _lib.check(lib.mtam_score32_train(_p(E), _p(pred), _pi(target), B, V, float(scale), _p(work), work.numel(),
+                                      _p(lse), _p(ce), _p(d_pred), _p(dE), _p(sq_partial),
+                                      0 if sq_partial is None else (sq_partial.numel() if n_sq is None else int(n_sq)),
+                                      _stream()), "mtam_score32_train")
+
+
 def score16_logits(E16, P16, B, V, logits, ld):
     lib = _lib.load()
     _lib.check(lib.mtam_score16_logits(_pb(E16), _pb(P16), B, V, _p(logits), ld, _stream()), "mtam_score16_logits")

@@ -1070,6 +1070,60 @@ def test_score32_row_ranges_combine_to_the_whole_catalog(ops, B, V, cuts):
     assert float((dE.double() - (G * scale).T @ P.double()).abs().max()) < 2e-5 * float(dE_w.abs().max())
 
 
+@pytest.mark.parametrize("B,V,fused", [(128, 3709, True), (128, 3712, True), (100, 1000, True), (37, 257, True),
+                                       (1, 5376, True), (128, 5377, False), (128, 7169, False), (129, 3709, False), (37, 63, False),
+                                       (128, 256, True), (128, 225, True), (128, 224, False)])
+def test_score32_train_one_call(ops, B, V, fused):
+    """mtam_score32_train: the loss terms and both scoring gradients in one call -- ONE launch (x3::train_small_kernel:
+    grid barrier, d_pred summed in slab order) when every slab gets a resident workgroup, lse + bwd otherwise.  Against
+    float64 products of the same fp32 operands and against the two-pass kernels; three calls in a row on the same work
+    buffer (the barrier words return to rest) give bit-identical results (no float atomics in the fused form)."""
+    assert ops.score32_train_is_fused(B, V) == fused
+    rng = np.random.default_rng(B * 7 + V)
+    E = dev((rng.standard_normal((V, D)) * 0.2).astype(np.float32))
+    P = dev(rng.standard_normal((B, D)).astype(np.float32))
+    target = rng.integers(0, V, B).astype(np.int32)
+    target[0], target[B - 1] = V - 1, 0
+    if B > 2:
+        target[1] = (V // 32) * 32 - 1 if V >= 64 else 1        # last row of the last full slab
+    tgt = dev(target)
+    z = lambda *s: torch.zeros(s, device="cuda")
+    scale = 1.0 / B
+    OFF = 1.0 / 1024            # d_pred is ACCUMULATED: it starts from this (small: the sums round at its ulp, 1e-10)
+    work = ops.score32_train_work(B, V)
+    outs = []
+    for _ in range(3):
+        lse, ce, d_pred = z(B), z(B), torch.full((B, D), OFF, device="cuda")
+        dE, sq = torch.full((V, D), 5.0, device="cuda"), z(ops.score32_sq_partials(V))
+        ops.score32_train(E, P, tgt, B, V, scale, work, lse, ce, d_pred, dE, sq)
+        outs.append((lse, ce, d_pred, dE, sq))
+    torch.cuda.synchronize()
+    lse, ce, d_pred, dE, sq = outs[0]
+    if fused:
+        for o in outs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
+    ref_logits = P.double() @ E.double().T
+    ref_lse = torch.logsumexp(ref_logits, 1)
+    ref_ce = ref_lse - ref_logits.gather(1, tgt.long()[:, None])[:, 0]
+    assert float((lse.double() - ref_lse).abs().max()) < 1e-5 * float(ref_lse.abs().max())
+    assert float((ce.double() - ref_ce).abs().max()) < 2e-5 * float(ref_lse.abs().max())
+    G = torch.exp(ref_logits - ref_lse[:, None])
+    G[torch.arange(B), tgt.long()] -= 1.0
+    G *= scale
+    ref_dpred, ref_dE = G @ E.double(), G.T @ P.double()
+    assert float((d_pred.double() - OFF - ref_dpred).abs().max()) < 2e-5 * float(ref_dpred.abs().max()) + 1e-8
+    assert float((dE.double() - ref_dE).abs().max()) < 2e-5 * float(ref_dE.abs().max())
+    assert abs(float(sq.double().sum()) - float((dE.double() ** 2).sum())) < 1e-5 * float((dE.double() ** 2).sum())
+    # the two-pass kernels on the same operands: equal to fp32 rounding
+    lse2, ce2, d_pred2, dE2 = z(B), z(B), z(B, D), z(V, D)
+    ops.score32_lse(E, P, tgt, B, V, z(ops.score32_partials(B, V)), lse2, ce2)
+    ops.score32_bwd(E, P, lse2, tgt, B, V, scale, d_pred2, dE2)
+    assert float((lse - lse2).abs().max()) <= 2e-6 * float(lse2.abs().max())
+    assert float((ce - ce2).abs().max()) <= 2e-5 * float(lse2.abs().max())
+    assert float((dE - dE2).abs().max()) <= 4e-6 * float(dE2.abs().max())
+    assert float((d_pred - OFF - d_pred2).abs().max()) <= 1e-5 * float(d_pred2.abs().max()) + 1e-8
+
+
 def test_score32_rejects_buffers_sized_under_the_other_form(ops):
     """The partial-buffer counts depend on the form (mtam_score32_set_split_min_rows is process-global state): a
     buffer sized under one form is REJECTED when the other is in force, not overrun -- and the backward's
