@@ -723,6 +723,17 @@ class TimeAwarePath(object):
             n_g = self.n_total
             n = ops.sqnorm_blocks(self.n_total)
         gb = self.gb(bt)
+        if self.optimizer == "adam" and n <= ops.adam_clip_max_partials() and \
+                os.environ.get("MTAM_CLIP_IN_ADAM", "1") != "0":
+            # no arrival ticket: the first launch only writes partials (and, in one more workgroup, advances the Adam
+            # state and reduces the loss); every workgroup of the optimizer launch forms the norm itself
+            ops.sqnorm_state_loss(self.flat_g, n_g, part, 0, bt.feed["lr"], self.adam_state, bt.l2_live,
+                                  bt.l2_live.numel(), bt.ce, bt.B, self.reg, 1.0 / gb,
+                                  None if self.loss_in_tail else bt.loss)
+            ops.adam_images_clip(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, part, n, self.clip,
+                                 self.scale, self.adam_state, self.n_dense, self.wimg_descs, copy16=self.item16,
+                                 copy_begin=self.tab_off["item"])
+            return
         ops.sqnorm_clip_scale(self.flat_g, n_g, part, 0, n, self.clip, self.scale, bt.feed["lr"],
                               self.adam_state, self.ticket, bt.l2_live, bt.l2_live.numel(), bt.ce, bt.B,
                               self.reg, 1.0 / gb, None if self.loss_in_tail else bt.loss)

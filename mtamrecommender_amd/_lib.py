@@ -119,6 +119,10 @@ SIGNATURES = {
     "mtam_adam": (c_int, [P, P, P, P, c_size_t, P, P, c_size_t, P]),
     "mtam_adam_bf16copy": (c_int, [P, P, P, P, c_size_t, P, P, c_size_t, P, c_size_t, P]),
     "mtam_adam_images": (c_int, [P, P, P, P, c_size_t, P, P, c_size_t, P, c_size_t, P, c_int, P]),
+    "mtam_adam_images_clip": (c_int, [P, P, P, P, c_size_t, P, c_int, c_float, P, P, c_size_t, P, c_size_t, P, c_int,
+                                      P]),
+    "mtam_adam_clip_max_partials": (c_int, []),
+    "mtam_sqnorm_state_loss": (c_int, [P, c_size_t, P, c_int, P, P, P, c_int, P, c_int, c_float, c_float, P, P]),
     "mtam_opt_update": (c_int, [c_int, P, P, P, P, c_size_t, P, P, c_size_t, c_size_t, P]),
     "mtam_gemm_tn_atomic_grouped": (c_int, [c_int, P, P]),
     "mtam_colsum_atomic_multi": (c_int, [c_int, P, P]),

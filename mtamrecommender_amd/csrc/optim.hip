@@ -224,6 +224,78 @@ __global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restric
   }
 }
 
+// sum of n floats in float64, by one 256-thread workgroup, the same order in every workgroup that runs it: per thread
+// in batches of eight loads (clamped index, masked value), wave shuffle, four waves through LDS
+__device__ __forceinline__ double block_sum_f64(const float *__restrict__ src, int n, double (&dred)[4]) {
+  double acc = 0.0;
+  for (int base = 0; base < n; base += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = src[min(base + (int)threadIdx.x + 256 * q, n - 1)];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc += (base + (int)threadIdx.x + 256 * q < n) ? (double)v[q] : 0.0;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  const double t = (dred[0] + dred[1]) + (dred[2] + dred[3]);
+  __syncthreads();
+  return t;
+}
+
+// The same step WITHOUT the ticket: workgroups 0 .. nb - 1 write their partial sums of squares and nothing else; one
+// more workgroup advances the Adam state and reduces the reported loss (neither depends on the norm).  The norm itself
+// is formed by the optimizer launch -- every one of its workgroups sums the partials (adam_kernel, norm_partials).
+// 2.6 us against 7.0 for sqnorm_clip_kernel at ml-1m sizes (61 blocks): the arrival ticket is a same-address atomic per
+// workgroup (~45 ns each, serialised) and the last workgroup's reduction a second dependent pass.
+__global__ __launch_bounds__(256) void sqnorm_state_loss_kernel(const float *__restrict__ g, size_t n,
+                                                                float *__restrict__ partials, int offset,
+                                                                const float *__restrict__ lr,
+                                                                float *__restrict__ adam_state,
+                                                                const float *__restrict__ l2_partial, int n_l2,
+                                                                const float *__restrict__ ce, int B, float reg,
+                                                                float ce_scale, float *__restrict__ loss) {
+  __shared__ float red[4];
+  __shared__ double dred[4];
+  if (blockIdx.x == gridDim.x - 1) {
+    if (adam_state && threadIdx.x == 0) {
+      const float b1 = adam_state[1], b2 = adam_state[2];
+      const float b1p = adam_state[4], b2p = adam_state[5];
+      adam_state[0] = lr[0] * sqrtf(1.0f - b2p) / (1.0f - b1p);
+      adam_state[4] = b1p * b1;
+      adam_state[5] = b2p * b2;
+    }
+    if (loss) {
+      // the reported loss (Model/base_model.py:322-326) from the per-row cross entropies and the lookups' L2 partials
+      const double l2 = 0.5 * block_sum_f64(l2_partial, n_l2, dred);
+      const double ces = block_sum_f64(ce, B, dred);
+      if (threadIdx.x == 0) {
+        loss[0] = (float)((double)reg * l2 + (double)ce_scale * ces);
+        loss[1] = (float)l2;
+        loss[2] = (float)((double)ce_scale * ces);
+      }
+    }
+    return;
+  }
+  const size_t base = (size_t)blockIdx.x * NORM_BLOCK;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_BLOCK / 1024; ++i) {
+    const size_t o = base + (size_t)(threadIdx.x + 256 * i) * 4;
+    if (o + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4 *>(g + o);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (size_t q = o; q < n && q < o + 4; ++q) s += g[q] * g[q];
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[offset + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // COPY: elements at or after copy_begin (the item table) are also written, rounded to nearest even, to the
 // bf16 scoring copy (csrc/score16.hip) -- 2 more bytes per element instead of a separate 6-byte pass.
 typedef __bf16 adam_bf16x4 __attribute__((ext_vector_type(4)));
@@ -247,7 +319,14 @@ struct AdamImages {
   int K[MTAM_MAX_WEIGHT_IMAGES], N[MTAM_MAX_WEIGHT_IMAGES];
   uint16_t *img[MTAM_MAX_WEIGHT_IMAGES], *img_r[MTAM_MAX_WEIGHT_IMAGES];
   int gru_which[MTAM_MAX_WEIGHT_IMAGES];      // 1 / 2: the GRU forward's fp32 register-order image (csrc/tagru.hip)
+  // mtam_adam_images_clip: non-NULL = EVERY workgroup derives the clip scale itself from these partial sums of
+  // squares (written by earlier launches of the step) instead of reading scale[0]; workgroup 0 publishes it
+  const float *norm_partials;
+  int n_norm;
+  float clip;
+  float *scale_out;
 };
+
 template <bool COPY, bool NT>
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ m,
                                                    float *__restrict__ v, const float *__restrict__ g, size_t n,
@@ -255,7 +334,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
                                                    const float *__restrict__ hyper, size_t sparse_begin,
                                                    uint16_t *__restrict__ copy16, size_t copy_begin,
                                                    AdamImages wi) {
-  const float sc = scale[0];
+  __shared__ double dred[4];
+  float sc;
+  if (wi.norm_partials) {                      // launch-uniform
+    const float norm = sqrtf((float)block_sum_f64(wi.norm_partials, wi.n_norm, dred));
+    sc = wi.clip * fminf(1.0f / norm, 1.0f / wi.clip);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      wi.scale_out[0] = sc;
+      wi.scale_out[1] = norm;
+    }
+  } else {
+    sc = scale[0];
+  }
   const float lr_t = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   const size_t base = (size_t)blockIdx.x * NORM_BLOCK;
@@ -579,10 +669,54 @@ extern "C" int mtam_adam_bf16copy(float *p, float *m, float *v, const float *g, 
   return MTAM_OK;
 }
 
+extern "C" int mtam_sqnorm_state_loss(const float *g, size_t n, float *partials, int offset, const float *lr,
+                                      float *adam_state, const float *l2_partial, int n_l2, const float *ce, int B,
+                                      float reg, float ce_scale, float *loss, void *stream) {
+  MTAM_CHECK_ARG(g && partials && n > 0 && offset >= 0, "sqnorm_state_loss: bad arguments");
+  MTAM_CHECK_ARG(!loss || (l2_partial && ce && B > 0 && n_l2 > 0), "sqnorm_state_loss: loss inputs missing");
+  MTAM_CHECK_ARG(mtam_aligned16(g), "sqnorm_state_loss: gradient must be 16-byte aligned");
+  MTAM_CHECK_ARG((lr == nullptr) == (adam_state == nullptr), "sqnorm_state_loss: lr and adam_state go together");
+  hipLaunchKernelGGL(sqnorm_state_loss_kernel, dim3(mtam_sqnorm_blocks(n) + 1), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g, n, partials, offset, lr, adam_state, l2_partial, n_l2, ce, B,
+                     reg, ce_scale, loss);
+  MTAM_CHECK_LAUNCH("sqnorm_state_loss");
+  return MTAM_OK;
+}
+
+// every workgroup of the optimizer launch sums the norm's partials itself: fine for thousands of them (ml-1m: 5,357,
+// 21 KB of L2 reads per workgroup), not for the 312 k blocks of a 10 M-row table
+extern "C" int mtam_adam_clip_max_partials(void) { return 1 << 14; }
+
+static int adam_images_launch(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
+                              const float *norm_partials, int n_norm, float clip, float *scale_out,
+                              const float *hyper, size_t sparse_begin, uint16_t *copy16, size_t copy_begin,
+                              const MtamWeightImages *w, int n_w, void *stream);
+
 extern "C" int mtam_adam_images(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
                                 const float *hyper, size_t sparse_begin, uint16_t *copy16, size_t copy_begin,
                                 const MtamWeightImages *w, int n_w, void *stream) {
-  MTAM_CHECK_ARG(p && m && v && g && scale && hyper && n > 0, "adam_images: bad arguments");
+  MTAM_CHECK_ARG(scale, "adam_images: bad arguments");
+  return adam_images_launch(p, m, v, g, n, scale, nullptr, 0, 0.f, nullptr, hyper, sparse_begin, copy16, copy_begin, w,
+                            n_w, stream);
+}
+
+extern "C" int mtam_adam_images_clip(float *p, float *m, float *v, const float *g, size_t n,
+                                     const float *norm_partials, int n_partials, float clip_norm, float *scale_out,
+                                     const float *hyper, size_t sparse_begin, uint16_t *copy16, size_t copy_begin,
+                                     const MtamWeightImages *w, int n_w, void *stream) {
+  MTAM_CHECK_ARG(norm_partials && scale_out && clip_norm > 0.f && n_partials > 0 &&
+                     n_partials <= mtam_adam_clip_max_partials(),
+                 "adam_images_clip: 1 .. %d partials, a positive clip norm and a 2-float scale_out",
+                 mtam_adam_clip_max_partials());
+  return adam_images_launch(p, m, v, g, n, nullptr, norm_partials, n_partials, clip_norm, scale_out, hyper,
+                            sparse_begin, copy16, copy_begin, w, n_w, stream);
+}
+
+static int adam_images_launch(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
+                              const float *norm_partials, int n_norm, float clip, float *scale_out,
+                              const float *hyper, size_t sparse_begin, uint16_t *copy16, size_t copy_begin,
+                              const MtamWeightImages *w, int n_w, void *stream) {
+  MTAM_CHECK_ARG(p && m && v && g && hyper && n > 0, "adam_images: bad arguments");
   MTAM_CHECK_ARG(mtam_aligned16(p) && mtam_aligned16(m) && mtam_aligned16(v) && mtam_aligned16(g) &&
                      (reinterpret_cast<uintptr_t>(copy16) & 7u) == 0,
                  "adam_images: buffers must be 16-byte aligned (the bf16 copy 8-byte)");
@@ -593,6 +727,7 @@ extern "C" int mtam_adam_images(float *p, float *m, float *v, const float *g, si
                  MTAM_MAX_WEIGHT_IMAGES);
   AdamImages wi{};
   wi.n = n_w;
+  wi.norm_partials = norm_partials; wi.n_norm = n_norm; wi.clip = clip; wi.scale_out = scale_out;
   wi.n_linear = (unsigned)mtam_sqnorm_blocks(n);
   const size_t dense_end = sparse_begin < n ? sparse_begin : n;
   for (int j = 0; j < n_w; ++j) {

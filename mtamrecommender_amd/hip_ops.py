@@ -477,6 +477,31 @@ def adam_images(p, m, v, g, n, scale, hyper, sparse_begin, descs, copy16=None, c
                                             ctypes.cast(arr, ctypes.c_void_p), n_w, _stream()), "mtam_adam_images")
 
 
+def adam_clip_max_partials():
+    return _lib.load().mtam_adam_clip_max_partials()
+
+
+def adam_images_clip(p, m, v, g, n, norm_partials, n_partials, clip_norm, scale_out, hyper, sparse_begin, descs,
+                     copy16=None, copy_begin=0):
+    """adam_images where every workgroup derives the clip scale from the norm's partials itself (no ticket launch
+    before it: sqnorm_state_loss writes the partials); scale_out <- (scale, norm).  ``descs``: None = no images."""
+    arr, n_w = descs if descs is not None else (None, 0)
+    _lib.check(_lib.load().mtam_adam_images_clip(_p(p), _p(m), _p(v), _p(g), n, _p(norm_partials), int(n_partials),
+                                                 float(clip_norm), _p(scale_out), _p(hyper), int(sparse_begin),
+                                                 _pb(copy16) if copy16 is not None else None, int(copy_begin),
+                                                 ctypes.cast(arr, ctypes.c_void_p) if arr is not None else None, n_w,
+                                                 _stream()), "mtam_adam_images_clip")
+
+
+def sqnorm_state_loss(g, n, partials, offset, lr, adam_state, l2_partial=None, n_l2=0, ce=None, B=0, reg=0.0,
+                      ce_scale=0.0, loss=None):
+    """Partial sums of squares of g's blocks -> partials[offset ..]; one more workgroup advances the Adam state and
+    reduces the reported loss.  No ticket, no scale: adam_images_clip forms the norm."""
+    _lib.check(_lib.load().mtam_sqnorm_state_loss(_p(g), n, _p(partials), int(offset), _p(lr), _p(adam_state),
+                                                  _p(l2_partial), n_l2, _p(ce), B, float(reg), float(ce_scale),
+                                                  _p(loss), _stream()), "mtam_sqnorm_state_loss")
+
+
 def seq_chain_gather_partials(B, L):
     return _lib.load().mtam_seq_chain_gather_partials(B, L)
 

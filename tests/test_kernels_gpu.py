@@ -1294,6 +1294,58 @@ def test_adam_rewrites_the_weight_images(ops):
         ops.adam_images(p2, m2, v2, dev(g), n, scale, hyper, blk, ops.weight_image_descs([mats[2] + (imgs[2],)]))
 
 
+@pytest.mark.parametrize("n_extra,with_images", [(0, True), (5357, True), (300, False), (16000, False), (17000, False)])
+def test_clip_inside_the_optimizer_launch_equals_the_ticket_pair(ops, n_extra, with_images):
+    """mtam_sqnorm_state_loss + mtam_adam_images_clip (no arrival ticket: partials only, then EVERY workgroup of the
+    optimizer launch sums them and derives the clip scale) against mtam_sqnorm_clip_scale + mtam_adam_images: the
+    same norm, scale, Adam state, loss, parameters, slots and images, bit for bit; three steps in a row."""
+    rng = np.random.default_rng(n_extra + 3)
+    blk = ops.adam_block()
+    n_dense, n = 5 * blk, 7 * blk + 128 * 11
+    nb = ops.sqnorm_blocks(n_dense)
+    n_part = nb + n_extra
+    mats = [(256, 16, 128), (2 * blk + 4, 128, 36)] if with_images else []
+    p0 = rng.standard_normal(n).astype(np.float32)
+    m0, v0 = (rng.standard_normal(n) * 0.1).astype(np.float32), rng.uniform(0, 0.1, n).astype(np.float32)
+    l2, ce = dev(rng.uniform(0, 2, 977).astype(np.float32)), dev(rng.uniform(0, 9, 37).astype(np.float32))
+    lr = dev(np.array([1e-3], np.float32))
+
+    def run(new):
+        p, m, v = dev(p0), dev(m0), dev(v0)
+        state = dev(np.array([0.0, 0.9, 0.999, 1e-8, 0.9, 0.999, 0.0, 0.0], np.float32))
+        scale, loss = torch.zeros(2, device="cuda"), torch.zeros(4, device="cuda")
+        ticket = torch.zeros(4, dtype=torch.int32, device="cuda")
+        imgs = [torch.full((3 * K * N,), 7.0, dtype=torch.bfloat16, device="cuda") for _, K, N in mats]
+        descs = ops.weight_image_descs([(b, K, N, im) for (b, K, N), im in zip(mats, imgs)]) if mats else None
+        out = []
+        for step in range(3):
+            g = dev((np.random.default_rng(step).standard_normal(n) * (3.0 if step == 1 else 0.01)).astype(np.float32))
+            part = torch.zeros(n_part + 4, device="cuda")
+            part[nb:n_part] = dev(np.random.default_rng(step + 9).uniform(0, 1e-3, n_extra).astype(np.float32))
+            if new:
+                ops.sqnorm_state_loss(g, n_dense, part, 0, lr, state, l2, l2.numel(), ce, ce.numel(), 1e-4, 1 / 37.0, loss)
+                ops.adam_images_clip(p, m, v, g, n, part, n_part, 5.0, scale, state, n_dense, descs)
+            else:
+                ops.sqnorm_clip_scale(g, n_dense, part, 0, n_part, 5.0, scale, lr, state, ticket, l2, l2.numel(), ce,
+                                      ce.numel(), 1e-4, 1 / 37.0, loss)
+                if descs is not None:
+                    ops.adam_images(p, m, v, g, n, scale, state, n_dense, descs)
+                else:
+                    ops.adam(p, m, v, g, n, scale, state, n_dense)
+            out.append([t.clone() for t in (p, m, v, scale, state, loss[:3])] + [im.clone() for im in imgs])
+        return out
+
+    if n_extra + nb > ops.adam_clip_max_partials():
+        with pytest.raises(RuntimeError):
+            run(True)
+        return
+    a, b = run(False), run(True)
+    for step, (x, y) in enumerate(zip(a, b)):
+        for i, (s, t) in enumerate(zip(x, y)):
+            assert torch.equal(s, t), (step, i)
+    assert float(a[1][3][0]) < 1.0 and float(a[0][3][0]) == 1.0      # step 1 is clipped, step 0 is not
+
+
 @pytest.mark.parametrize("x3", [False, True])
 @pytest.mark.parametrize("R,n_kv,n_x", [(6400, 256, 384), (100, 512, 384), (33, 0, 384), (777, 256, 640)])
 def test_seq_chain_fwd_matches_the_three_products(ops, R, n_kv, n_x, x3):
