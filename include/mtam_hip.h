@@ -233,6 +233,32 @@ int mtam_emb_scatter_add_bwd_range(const float *d_item_cat, const float *d_z, co
                                    int L, float reg, int with_user, float *g_item, int item_rows, float *g_cat,
                                    int cat_rows, float *g_pos, int pos_rows, float *g_user, int user_rows,
                                    float *slot_sq_partial, int item_lo, int item_hi, int item_only, void *stream);
+/* The scatter-add with the clip's partial pass RIDING ALONG (mtam_sqnorm_state_loss as extra workgroups of this
+ * launch, on the CUs it leaves idle: the dense gradient `norm->g` must be complete before the launch, i.e. the weight
+ * gradients come first): partials[offset + i] = sum of squares of 4,096-float block i of g[0 .. n); the Adam state
+ * advanced (lr, adam_state; both NULL = not); loss[0..2] = reg * l2 + ce_scale * sum(ce), l2, ce_scale * sum(ce)
+ * (NULL = not).  One launch and its gap less per step (2.6 + ~1 us at ml-1m sizes). */
+typedef struct MtamNormRider {
+  const float *g;
+  size_t n;
+  float *partials;
+  int offset;
+  const float *lr;
+  float *adam_state;
+  const float *l2_partial;
+  int n_l2;
+  const float *ce;
+  int B;
+  float reg, ce_scale;
+  float *loss;
+} MtamNormRider;
+int mtam_emb_scatter_add_bwd_norm(const float *d_item_cat, const float *d_z, const float *W4, const float *d_pos,
+                                  const float *item_cat, const float *pos, const float *pos_table, const float *user,
+                                  const int32_t *item_ids, const int32_t *cat_ids, const int32_t *pos_ids,
+                                  const int32_t *user_ids, const int32_t *seq_len, int B, int L, float reg,
+                                  int with_user, float *g_item, int item_rows, float *g_cat, int cat_rows,
+                                  float *g_pos, int pos_rows, float *g_user, int user_rows, float *slot_sq_partial,
+                                  const MtamNormRider *norm, void *stream);
 /* out [n, 128]: row ids[i] of the catalog if it lies in the range [row0, row0 + nrows) that table_rows holds (its
  * first row is catalog row row0), else zeros.  Data-parallel "sharded-table" exchange: the owners' rows of every
  * rank's history ids, summed by a reduce-scatter (each row has exactly one owner), replace a replicated item table as

@@ -711,9 +711,30 @@ class TimeAwarePath(object):
                                 d_z=bt.d_z if fused_scatter else None,
                                 W4=self.seg("dense4emb/w") if fused_scatter else None,
                                 item_range=(self.sharded_scoring.row_lo, self.sharded_scoring.row_hi)
-                                if self.sharded_scoring is not None else None)
+                                if self.sharded_scoring is not None else None,
+                                norm=self._norm_rider(bt))
 
     # ------------------------------------------------------------------ update
+    def _clip_in_adam(self, n_partials):
+        """The clip scale formed inside the optimizer launch (no ticket launch before it)."""
+        return self.optimizer == "adam" and n_partials <= ops.adam_clip_max_partials() and \
+            os.environ.get("MTAM_CLIP_IN_ADAM", "1") != "0"
+
+    def _norm_rider(self, bt):
+        """Single-GPU training steps: the clip's partial pass over the dense gradient (+ Adam state, + reported loss)
+        rides in the scatter-add launch, the last launch of the backward -- the weight gradients are complete by
+        then and nothing is exchanged between backward and update.  None: clip_and_apply launches it."""
+        bt.norm_rode = False
+        if not (getattr(bt, "train_step_bwd", False) and self.tf_compat and self.allreduce_fn is None and
+                self.sharded is None and self.sharded_scoring is None and not self.loss_in_tail and
+                self._clip_in_adam(self.nb_dense + self.nb_item + bt.n_slot) and
+                os.environ.get("MTAM_NORM_RIDER", "1") != "0"):
+            return None
+        bt.norm_rode = True
+        return dict(g=self.flat_g, n=self.n_dense, partials=bt.norm_partial, offset=0, lr=bt.feed["lr"],
+                    adam_state=self.adam_state, l2_partial=bt.l2_live, ce=bt.ce, B=bt.B, reg=self.reg,
+                    ce_scale=1.0 / self.gb(bt), loss=bt.loss)
+
     def clip_and_apply(self, bt):
         part = bt.norm_partial
         if self.tf_compat:
@@ -723,13 +744,15 @@ class TimeAwarePath(object):
             n_g = self.n_total
             n = ops.sqnorm_blocks(self.n_total)
         gb = self.gb(bt)
-        if self.optimizer == "adam" and n <= ops.adam_clip_max_partials() and \
-                os.environ.get("MTAM_CLIP_IN_ADAM", "1") != "0":
+        if self._clip_in_adam(n):
             # no arrival ticket: the first launch only writes partials (and, in one more workgroup, advances the Adam
-            # state and reduces the loss); every workgroup of the optimizer launch forms the norm itself
-            ops.sqnorm_state_loss(self.flat_g, n_g, part, 0, bt.feed["lr"], self.adam_state, bt.l2_live,
-                                  bt.l2_live.numel(), bt.ce, bt.B, self.reg, 1.0 / gb,
-                                  None if self.loss_in_tail else bt.loss)
+            # state and reduces the loss) -- or has already ridden in the backward's last launch; every workgroup of the
+            # optimizer launch forms the norm itself
+            if not getattr(bt, "norm_rode", False):
+                ops.sqnorm_state_loss(self.flat_g, n_g, part, 0, bt.feed["lr"], self.adam_state, bt.l2_live,
+                                      bt.l2_live.numel(), bt.ce, bt.B, self.reg, 1.0 / gb,
+                                      None if self.loss_in_tail else bt.loss)
+            bt.norm_rode = False
             ops.adam_images_clip(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, part, n, self.clip,
                                  self.scale, self.adam_state, self.n_dense, self.wimg_descs, copy16=self.item16,
                                  copy_begin=self.tab_off["item"])
@@ -756,14 +779,20 @@ class TimeAwarePath(object):
                        self.scale, bt.feed["lr"], self.n_dense, self.tab_off["item"])
         self.refresh_derived()
 
-    def forward_backward_kernels(self, bt):
+    def forward_backward_kernels(self, bt, update_follows=False):
+        """``update_follows``: clip_and_apply comes right after (train_kernels on one GPU) -- the clip's partial pass,
+        the Adam state's advance and the loss reduction may then ride in the backward's last launch."""
         bt.train_step = True             # forward and backward back to back: the scoring passes may merge
         try:
             self.forward(bt, training=True)
         finally:
             bt.train_step = False
         self.loss_and_logit_grad(bt)
-        self.backward(bt)
+        bt.train_step_bwd = bool(update_follows)
+        try:
+            self.backward(bt)
+        finally:
+            bt.train_step_bwd = False
 
     # the two halves of a step under data-parallel row-sharded scoring (the scoring passes and their collectives run
     # between them: data_parallel.ShardedScoringExchange.score)
@@ -791,7 +820,7 @@ class TimeAwarePath(object):
             self.backward_from_pred_kernels(bt)
             self.sharded_scoring.exchange_and_apply(bt)
             return
-        self.forward_backward_kernels(bt)
+        self.forward_backward_kernels(bt, update_follows=self.sharded is None and self.allreduce_fn is None)
         if self.sharded is not None:
             self.sharded.exchange_and_apply(bt)
             return

@@ -43,6 +43,8 @@ SIGNATURES = {
                                                P, c_int, P, c_int, P, c_int, P, c_int, P, P]),
     "mtam_emb_scatter_add_bwd_range": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
                                                P, c_int, P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, P]),
+    "mtam_emb_scatter_add_bwd_norm": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_int,
+                                              P, c_int, P, c_int, P, c_int, P, c_int, P, P, P]),
     "mtam_rows_gather_range": (c_int, [P, c_int, c_int, P, ctypes.c_long, P, P]),
     "mtam_seq_chain_gather_partials": (c_int, [c_int, c_int]),
     "mtam_seq_chain_gather_fwd": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int,
@@ -140,6 +142,13 @@ class WeightImages(ctypes.Structure):
     """MtamWeightImages (include/mtam_hip.h): one weight matrix of the flat space and where its bf16 images go."""
     _fields_ = [("begin", c_size_t), ("K", c_int), ("N", c_int), ("images", c_void_p), ("images_r", c_void_p),
                 ("gru_which", c_int)]
+
+
+class NormRider(ctypes.Structure):
+    """MtamNormRider (include/mtam_hip.h): the clip's partial pass riding in the scatter-add launch."""
+    _fields_ = [("g", c_void_p), ("n", c_size_t), ("partials", c_void_p), ("offset", c_int), ("lr", c_void_p),
+                ("adam_state", c_void_p), ("l2_partial", c_void_p), ("n_l2", c_int), ("ce", c_void_p), ("B", c_int),
+                ("reg", c_float), ("ce_scale", c_float), ("loss", c_void_p)]
 
 
 class ColsumJob(ctypes.Structure):

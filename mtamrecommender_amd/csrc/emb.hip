@@ -147,6 +147,11 @@ struct ScatterArgs {
   // [item_lo, item_hi) are added (the rank's own rows of the item gradient); n_cat = 0 drops the category chunks
   // (n_tr = n_user = 0 the others) when another rank's slots are applied to the item rows alone
   int item_lo, item_hi, n_cat;
+  // mtam_emb_scatter_add_bwd_norm: workgroups past the padded-slot one do what csrc/optim.hip's
+  // sqnorm_state_loss_kernel does (partial sums of squares of the DENSE gradient, complete by now; the Adam state;
+  // the reported loss) on CUs this launch leaves idle -- one launch and its gap less per step.  nr.g NULL: none
+  MtamNormRider nr;
+  int nr_blocks;
 };
 
 // Scatter-add with a per-workgroup duplicate pre-reduction.
@@ -175,6 +180,75 @@ constexpr int NHW = SCATTER_THREADS / 32;     // half waves per workgroup
 constexpr int SPH = CH / NHW;                 // slots per half wave (4)
 constexpr int NBUCKET = 256;
 
+// sum of n floats in float64 by the whole 1024-thread workgroup (one fixed order)
+__device__ __forceinline__ double rider_sum_f64(const float *__restrict__ src, int n, double *dred) {
+  double acc = 0.0;
+  for (int base = 0; base < n; base += SCATTER_THREADS * 4) {
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = src[min(base + (int)threadIdx.x + SCATTER_THREADS * q, n - 1)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc += (base + (int)threadIdx.x + SCATTER_THREADS * q < n) ? (double)v[q] : 0.0;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < SCATTER_THREADS / 64; ++w) t += dred[w];
+  return t;
+}
+
+// Rider workgroup r: four 4,096-float blocks of the dense gradient (one per 256 threads; the arithmetic of
+// csrc/optim.hip's sqnorm kernels), or -- the last one -- the Adam state and the reported loss.
+__device__ __forceinline__ void norm_rider(const ScatterArgs &p, int r, float *lds) {
+  const MtamNormRider &nr = p.nr;
+  constexpr int BLOCK = 4096;
+  const int tid = threadIdx.x;
+  if (r == (p.nr_blocks + 3) / 4) {
+    if (nr.adam_state && tid == 0) {
+      const float b1 = nr.adam_state[1], b2 = nr.adam_state[2];
+      const float b1p = nr.adam_state[4], b2p = nr.adam_state[5];
+      nr.adam_state[0] = nr.lr[0] * sqrtf(1.0f - b2p) / (1.0f - b1p);
+      nr.adam_state[4] = b1p * b1;
+      nr.adam_state[5] = b2p * b2;
+    }
+    if (nr.loss) {
+      double *dred = reinterpret_cast<double *>(lds);
+      const double l2 = 0.5 * rider_sum_f64(nr.l2_partial, nr.n_l2, dred);
+      const double ces = rider_sum_f64(nr.ce, nr.B, dred);
+      if (tid == 0) {
+        nr.loss[0] = (float)((double)nr.reg * l2 + (double)nr.ce_scale * ces);
+        nr.loss[1] = (float)l2;
+        nr.loss[2] = (float)((double)nr.ce_scale * ces);
+      }
+    }
+    return;
+  }
+  const int sub = tid >> 8, t = tid & 255, block = 4 * r + sub;
+  const size_t base = (size_t)block * BLOCK;
+  float s = 0.f;
+  if (block < p.nr_blocks) {
+#pragma unroll
+    for (int i = 0; i < BLOCK / 1024; ++i) {
+      const size_t o = base + (size_t)(t + 256 * i) * 4;
+      if (o + 3 < nr.n) {
+        const float4 v = *reinterpret_cast<const float4 *>(nr.g + o);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      } else {
+        for (size_t q = o; q < nr.n && q < o + 4; ++q) s += nr.g[q] * nr.g[q];
+      }
+    }
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) lds[tid >> 6] = s;
+  __syncthreads();
+  if (t == 0 && block < p.nr_blocks)
+    nr.partials[nr.offset + block] = (lds[4 * sub] + lds[4 * sub + 1]) + (lds[4 * sub + 2] + lds[4 * sub + 3]);
+}
+
 __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArgs p) {
   __shared__ float stage[CH][D];               // 64 KB: rows of the follower slots
   __shared__ unsigned long long hkey[NBUCKET]; // min over the bucket of (slot << 32 | id)
@@ -187,6 +261,10 @@ __global__ __launch_bounds__(SCATTER_THREADS) void emb_scatter_kernel(ScatterArg
   const int R = p.B * p.L;
   const int n_work = p.n_rm + p.n_cat + p.n_tr + p.n_user;
 
+  if ((int)blockIdx.x > n_work) {
+    norm_rider(p, blockIdx.x - n_work - 1, &stage[0][0]);
+    return;
+  }
   if ((int)blockIdx.x == n_work) {
     // Padded slots: every one of them holds row 0 of its table and a zero upstream
     // gradient, so their contributions collapse to n_pad * reg * row0 per table.
@@ -553,6 +631,14 @@ extern "C" int mtam_emb_scatter_add_bwd_fused(const float *d_item_cat, const flo
                                         stream);
 }
 
+static int scatter_launch(const float *d_item_cat, const float *d_z, const float *W4, const float *d_pos,
+                          const float *item_cat, const float *pos, const float *pos_table, const float *user,
+                          const int32_t *item_ids, const int32_t *cat_ids, const int32_t *pos_ids,
+                          const int32_t *user_ids, const int32_t *seq_len, int B, int L, float reg, int with_user,
+                          float *g_item, int item_rows, float *g_cat, int cat_rows, float *g_pos, int pos_rows,
+                          float *g_user, int user_rows, float *slot_sq_partial, int item_lo, int item_hi, int item_only,
+                          const MtamNormRider *norm, void *stream);
+
 extern "C" int mtam_emb_scatter_add_bwd_range(const float *d_item_cat, const float *d_z, const float *W4,
                                               const float *d_pos, const float *item_cat, const float *pos,
                                               const float *pos_table, const float *user, const int32_t *item_ids,
@@ -562,6 +648,37 @@ extern "C" int mtam_emb_scatter_add_bwd_range(const float *d_item_cat, const flo
                                               float *g_pos, int pos_rows, float *g_user, int user_rows,
                                               float *slot_sq_partial, int item_lo, int item_hi, int item_only,
                                               void *stream) {
+  return scatter_launch(d_item_cat, d_z, W4, d_pos, item_cat, pos, pos_table, user, item_ids, cat_ids, pos_ids, user_ids,
+                        seq_len, B, L, reg, with_user, g_item, item_rows, g_cat, cat_rows, g_pos, pos_rows, g_user,
+                        user_rows, slot_sq_partial, item_lo, item_hi, item_only, nullptr, stream);
+}
+
+extern "C" int mtam_emb_scatter_add_bwd_norm(const float *d_item_cat, const float *d_z, const float *W4,
+                                             const float *d_pos, const float *item_cat, const float *pos,
+                                             const float *pos_table, const float *user, const int32_t *item_ids,
+                                             const int32_t *cat_ids, const int32_t *pos_ids,
+                                             const int32_t *user_ids, const int32_t *seq_len, int B, int L, float reg,
+                                             int with_user, float *g_item, int item_rows, float *g_cat, int cat_rows,
+                                             float *g_pos, int pos_rows, float *g_user, int user_rows,
+                                             float *slot_sq_partial, const MtamNormRider *norm, void *stream) {
+  MTAM_CHECK_ARG(norm && norm->g && norm->partials && norm->n > 0 && norm->offset >= 0 && mtam_aligned16(norm->g),
+                 "emb_scatter (norm rider): g (16-byte aligned), n and partials are required");
+  MTAM_CHECK_ARG(!norm->loss || (norm->l2_partial && norm->ce && norm->B > 0 && norm->n_l2 > 0),
+                 "emb_scatter (norm rider): loss inputs missing");
+  MTAM_CHECK_ARG((norm->lr == nullptr) == (norm->adam_state == nullptr),
+                 "emb_scatter (norm rider): lr and adam_state go together");
+  return scatter_launch(d_item_cat, d_z, W4, d_pos, item_cat, pos, pos_table, user, item_ids, cat_ids, pos_ids, user_ids,
+                        seq_len, B, L, reg, with_user, g_item, item_rows, g_cat, cat_rows, g_pos, pos_rows, g_user,
+                        user_rows, slot_sq_partial, 0, item_rows, 0, norm, stream);
+}
+
+static int scatter_launch(const float *d_item_cat, const float *d_z, const float *W4, const float *d_pos,
+                          const float *item_cat, const float *pos, const float *pos_table, const float *user,
+                          const int32_t *item_ids, const int32_t *cat_ids, const int32_t *pos_ids,
+                          const int32_t *user_ids, const int32_t *seq_len, int B, int L, float reg, int with_user,
+                          float *g_item, int item_rows, float *g_cat, int cat_rows, float *g_pos, int pos_rows,
+                          float *g_user, int user_rows, float *slot_sq_partial, int item_lo, int item_hi, int item_only,
+                          const MtamNormRider *norm, void *stream) {
   MTAM_CHECK_ARG(B > 0 && L > 0, "emb_scatter: B and L must be positive");
   MTAM_CHECK_ARG((long)B * L * 3 + B < 0x3fffffffL, "emb_scatter: batch too large");
   MTAM_CHECK_ARG(0 <= item_lo && item_lo <= item_hi && item_hi <= item_rows, "emb_scatter: bad item row range [%d, %d)",
@@ -573,7 +690,7 @@ extern "C" int mtam_emb_scatter_add_bwd_range(const float *d_item_cat, const flo
     ScatterArgs a{d_item_cat, nullptr, item_cat, nullptr, nullptr, item_ids, nullptr, nullptr, nullptr, seq_len,
                   B, L, 0, reg, g_item, nullptr, nullptr, nullptr, item_rows, 1, 1, 1, slot_sq_partial,
                   scatter_rm_chunks(B, L), 0, 0, mtam_emb_scatter_partials(B, L), nullptr, nullptr, nullptr,
-                  item_lo, item_hi, 0};
+                  item_lo, item_hi, 0, MtamNormRider{}, 0};
     hipLaunchKernelGGL(emb_scatter_kernel, dim3(a.n_rm + 1), dim3(SCATTER_THREADS), 0, static_cast<hipStream_t>(stream), a);
     MTAM_CHECK_LAUNCH("emb_scatter");
     return MTAM_OK;
@@ -590,9 +707,15 @@ extern "C" int mtam_emb_scatter_add_bwd_range(const float *d_item_cat, const flo
                 item_rows, cat_rows, pos_rows, user_rows, slot_sq_partial,
                 scatter_rm_chunks(B, L), scatter_tr_chunks(B, L), with_user ? scatter_user_chunks(B) : 0,
                 mtam_emb_scatter_partials(B, L), pos ? nullptr : pos_table, d_item_cat ? nullptr : d_z,
-                d_item_cat ? nullptr : W4, item_lo, item_hi, scatter_rm_chunks(B, L)};
-  hipLaunchKernelGGL(emb_scatter_kernel, dim3(a.n_rm + a.n_cat + a.n_tr + a.n_user + 1), dim3(SCATTER_THREADS), 0,
-                     static_cast<hipStream_t>(stream), a);
+                d_item_cat ? nullptr : W4, item_lo, item_hi, scatter_rm_chunks(B, L), MtamNormRider{}, 0};
+  int riders = 0;
+  if (norm) {
+    a.nr = *norm;
+    a.nr_blocks = (int)((norm->n + 4095) / 4096);
+    riders = (a.nr_blocks + 3) / 4 + 1;
+  }
+  hipLaunchKernelGGL(emb_scatter_kernel, dim3(a.n_rm + a.n_cat + a.n_tr + a.n_user + 1 + riders),
+                     dim3(SCATTER_THREADS), 0, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("emb_scatter");
   return MTAM_OK;
 }

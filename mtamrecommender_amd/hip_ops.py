@@ -132,12 +132,32 @@ def emb_scatter_partials(B, L):
 
 def emb_scatter_add_bwd(d_ic, d_pos, ic, pos, user, item_ids, cat_ids, pos_ids, user_ids, seq_len, B, L,
                         reg, with_user, g_item, g_cat, g_pos, g_user, slot_sq_partial, pos_table=None, d_z=None,
-                        W4=None, item_range=None):
+                        W4=None, item_range=None, norm=None):
     """pos_table given (and pos None): the looked-up position rows were never written out; their L2 term reads
     the table through the ids (steps whose forward is seq_chain_gather_fwd).  d_z and W4 given (and d_ic None): the
     [item | category] gradient rows are computed inside the kernel, d_z . W4^T per 128-slot chunk.
-    item_range = (lo, hi): only item slots with lo <= id < hi are added (a data-parallel rank's own item rows)."""
+    item_range = (lo, hi): only item slots with lo <= id < hi are added (a data-parallel rank's own item rows).
+    norm = dict(g, n, partials, offset, lr, adam_state, l2_partial, ce, B, reg, ce_scale, loss): what
+    sqnorm_state_loss does rides along as extra workgroups (mtam_emb_scatter_add_bwd_norm)."""
     lib = _lib.load()
+    if norm is not None:
+        assert item_range is None
+        nr = _lib.NormRider()
+        nr.g, nr.n, nr.partials, nr.offset = norm["g"].data_ptr(), int(norm["n"]), norm["partials"].data_ptr(), int(norm["offset"])
+        nr.lr = norm["lr"].data_ptr() if norm.get("lr") is not None else None
+        nr.adam_state = norm["adam_state"].data_ptr() if norm.get("adam_state") is not None else None
+        l2, ce, loss = norm.get("l2_partial"), norm.get("ce"), norm.get("loss")
+        nr.l2_partial, nr.n_l2 = (l2.data_ptr(), l2.numel()) if l2 is not None else (None, 0)
+        nr.ce, nr.B = (ce.data_ptr(), int(norm["B"])) if ce is not None else (None, 0)
+        nr.reg, nr.ce_scale = float(norm.get("reg", 0.0)), float(norm.get("ce_scale", 0.0))
+        nr.loss = loss.data_ptr() if loss is not None else None
+        rc = lib.mtam_emb_scatter_add_bwd_norm(
+            _p(d_ic), _p(d_z), _p(W4), _p(d_pos), _p(ic), _p(pos), _p(pos_table), _p(user), _pi(item_ids),
+            _pi(cat_ids), _pi(pos_ids), _pi(user_ids), _pi(seq_len), B, L, float(reg), int(with_user), _p(g_item),
+            g_item.shape[0], _p(g_cat), g_cat.shape[0], _p(g_pos), g_pos.shape[0], _p(g_user), g_user.shape[0],
+            _p(slot_sq_partial), ctypes.byref(nr), _stream())
+        _lib.check(rc, "mtam_emb_scatter_add_bwd_norm")
+        return
     if item_range is not None:
         rc = lib.mtam_emb_scatter_add_bwd_range(
             _p(d_ic), _p(d_z), _p(W4), _p(d_pos), _p(ic), _p(pos), _p(pos_table), _p(user), _pi(item_ids),

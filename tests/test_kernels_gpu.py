@@ -282,6 +282,49 @@ def test_emb_scatter_add_fused_sources(ops, B, L, with_user):
     assert abs(float(part.double().sum()) - float(part_ref.double().sum())) < 1e-5 * float(part_ref.double().sum())
 
 
+@pytest.mark.parametrize("B,L,n_g", [(128, 50, 61 * 4096), (5, 7, 4096 * 3 + 1234), (33, 50, 100)])
+def test_emb_scatter_add_with_the_norm_rider(ops, B, L, n_g):
+    """mtam_emb_scatter_add_bwd_norm: the scatter-add is unchanged and the riding workgroups do what
+    mtam_sqnorm_state_loss does -- the same partials bit for bit (the same per-block arithmetic), the same Adam state,
+    the loss to float64-summation rounding (1024 threads sum it in another order)."""
+    tabs, ids, uid, sl = _emb_case(B, L, B * 10 + L + 5)
+    rng = np.random.default_rng(B + 5 * L)
+    R = B * L
+    live = (np.arange(L)[None, :] < sl[:, None]).reshape(R, 1)
+    d_ic = dev((rng.standard_normal((R, 2 * D)) * live).astype(np.float32))
+    d_pos = dev((rng.standard_normal((R, D)) * live).astype(np.float32))
+    I, C, P, U = tabs[0][ids[0].ravel()], tabs[1][ids[1].ravel()], tabs[2][ids[2].ravel()], tabs[3][uid]
+    ic = dev(np.concatenate([I, C], axis=1))
+    g0 = [rng.standard_normal(t.shape).astype(np.float32) for t in tabs]
+    args = (dev(ids[0]), dev(ids[1]), dev(ids[2]), dev(uid), dev(sl), B, L, 0.37, 1)
+    gd = dev(rng.standard_normal(n_g).astype(np.float32))
+    l2, ce = dev(rng.uniform(0, 2, 4832).astype(np.float32)), dev(rng.uniform(0, 9, B).astype(np.float32))
+    lr = dev(np.array([1e-3], np.float32))
+    nb = ops.sqnorm_blocks(n_g)
+    out = []
+    for ride in (False, True):
+        g = [dev(x).clone() for x in g0]
+        part = torch.zeros(ops.emb_scatter_partials(B, L), device="cuda")
+        npart = torch.full((nb + 7,), 3.0, device="cuda")
+        state = dev(np.array([0.0, 0.9, 0.999, 1e-8, 0.81, 0.998, 0.0, 0.0], np.float32))
+        loss = torch.zeros(4, device="cuda")
+        norm = dict(g=gd, n=n_g, partials=npart, offset=2, lr=lr, adam_state=state, l2_partial=l2, ce=ce, B=B,
+                    reg=1e-4, ce_scale=1.0 / B, loss=loss)
+        ops.emb_scatter_add_bwd(d_ic, d_pos, ic, dev(P), dev(U), *args, g[0], g[1], g[2], g[3], part,
+                                norm=norm if ride else None)
+        if not ride:
+            ops.sqnorm_state_loss(gd, n_g, npart, 2, lr, state, l2, l2.numel(), ce, B, 1e-4, 1.0 / B, loss)
+        out.append((g, part, npart, state, loss))
+    (g_a, part_a, np_a, st_a, loss_a), (g_b, part_b, np_b, st_b, loss_b) = out
+    for x, y in zip(g_a, g_b):
+        assert rel_err(y.cpu().numpy(), x.cpu().numpy()) < 1e-5          # float atomics: order-dependent rounding
+    assert abs(float(part_a.double().sum()) - float(part_b.double().sum())) < 1e-5 * float(part_a.double().sum())
+    assert torch.equal(np_a, np_b) and float(np_b[0]) == 3.0 and float(np_b[2 + nb]) == 3.0
+    assert abs(float(np_b[2:2 + nb].double().sum()) - float((gd.double() ** 2).sum())) < 1e-5 * float((gd.double() ** 2).sum())
+    assert torch.equal(st_a, st_b) and float(st_b[4]) != 0.81
+    assert float((loss_a[:3] - loss_b[:3]).abs().max()) <= 1e-6 * float(loss_a[:3].abs().max())
+
+
 def test_rows_gather_range(ops):
     """mtam_rows_gather_range: the rows of a ROW RANGE by catalog row number, zeros for rows outside it -- summed over
     the ranges of a partition every id gets exactly its row (what the "sharded-table" reduce-scatter relies on)."""
