@@ -533,6 +533,7 @@ int mtam_score32_bwd_range(const float *E, const float *pred, const float *lse, 
  * mtam_score32_lse followed by mtam_score32_bwd.  `work`: mtam_score32_train_work_floats(B, V) floats, 16-byte aligned,
  * prepared ONCE by mtam_score32_train_work_init (the fused form's exchange buffers must start as "nothing published")
  * and then left to mtam_score32_train; one buffer serves one (B, V) and one stream. */
+void mtam_score32_set_fused(int on);      /* run-time form of MTAM_SCORE32_FUSED; work buffers are sized per form */
 int mtam_score32_train_is_fused(int B, int V);
 long mtam_score32_train_work_floats(int B, int V);
 int mtam_score32_train_work_init(float *work, long n_work, int B, int V, void *stream);

@@ -107,6 +107,7 @@ SIGNATURES = {
     "mtam_score32_lse_range": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int, P, P, P]),
     "mtam_score32_bwd_range": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, c_int, P]),
     "mtam_score32_bwd": (c_int, [P, P, P, P, c_int, c_int, c_float, P, P, P, c_int, P]),
+    "mtam_score32_set_fused": (None, [c_int]),
     "mtam_score32_train_is_fused": (c_int, [c_int, c_int]),
     "mtam_score32_train_work_floats": (ctypes.c_long, [c_int, c_int]),
     "mtam_score32_train_work_init": (c_int, [P, ctypes.c_long, c_int, c_int, P]),

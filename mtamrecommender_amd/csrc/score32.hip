@@ -1289,15 +1289,19 @@ int cu_count() {
 // the one-launch form (x3::train_small_kernel): one batch tile, every slab a resident workgroup of its own
 // (MTAM_SCORE32_FUSED=0 turns it off; processes SHARING a GPU must turn it off -- their grids would wait on each
 // other's CUs)
+int g_fused = -1;               // -1: MTAM_SCORE32_FUSED (read once); mtam_score32_set_fused() overrides
 bool small_form(int B, int V) {
-  static const bool on = [] {
+  if (g_fused < 0) {
     const char *e = getenv("MTAM_SCORE32_FUSED");
-    return !(e && e[0] == '0');
-  }();
+    g_fused = (e && e[0] == '0') ? 0 : 1;
+  }
+  const bool on = g_fused != 0;
   const int G = slabs_of(V);
   return on && use_split(V) && B <= BT && G >= 8 && G <= min(cu_count() / 8 * 7, x3::SMALL_MAX_G);      // (CUs to spare)
 }
 }  // namespace
+
+extern "C" void mtam_score32_set_fused(int on) { g_fused = on ? 1 : 0; }
 
 extern "C" int mtam_score32_train_is_fused(int B, int V) { return (B > 0 && V > 0 && small_form(B, V)) ? 1 : 0; }
 

@@ -575,6 +575,11 @@ def score32_bwd(E, pred, lse, target, B, V, scale, d_pred, dE, sq_partial=None, 
                "mtam_score32_bwd")
 
 
+def score32_set_fused(on):
+    """Run-time form of MTAM_SCORE32_FUSED (process-global): whether score32_train may run as one launch."""
+    _lib.load().mtam_score32_set_fused(1 if on else 0)
+
+
 def score32_train_is_fused(B, V):
     """Whether score32_train runs as ONE launch at this size (csrc/score32.hip, x3::train_small_kernel)."""
     return bool(_lib.load().mtam_score32_train_is_fused(int(B), int(V)))

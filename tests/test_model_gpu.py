@@ -154,6 +154,36 @@ def test_three_adam_steps_track_the_oracle(hip_lib, tmp_path):
         assert (d > 2e-5).mean() < 2e-3, name
 
 
+@pytest.mark.parametrize("switch", ["MTAM_CLIP_IN_ADAM", "MTAM_NORM_RIDER", "score32_fused"])
+def test_step_switches_give_the_same_training(hip_lib, tmp_path, monkeypatch, switch):
+    """The step's merged launches against the forms they replace, through model.train(): the clip scale formed inside
+    the optimizer launch (MTAM_CLIP_IN_ADAM=0: ticket launch + Adam), its partial pass riding in the scatter-add launch
+    (MTAM_NORM_RIDER=0: a launch of its own), training's scoring as one launch (off: lse + finish + backward).  Same
+    records, same weights, five steps (eager, capture, replays): the same losses and parameters to fp32 rounding."""
+    from mtamrecommender_amd import hip_ops as ops
+    B, L = 128, 50
+    runs = []
+    for off in (False, True):
+        if off and switch == "score32_fused":
+            ops.score32_set_fused(False)
+        elif off:
+            monkeypatch.setenv(switch, "0")
+        try:
+            model, FLAGS, records = build(tmp_path, B, L, 1, 1, items=3706)
+            assert ops.score32_train_is_fused(B, 3709) == (not (off and switch == "score32_fused"))
+            losses = [model.train(model.sess, records, 1e-3)[0] for _ in range(5)]
+            runs.append((losses, model.get_variables(), float(model.path.scale[1])))
+        finally:
+            ops.score32_set_fused(True)
+            monkeypatch.delenv(switch, raising=False)
+    (la, va, na), (lb, vb, nb) = runs
+    assert all(abs(x - y) <= 2e-5 * abs(x) for x, y in zip(la, lb)), (la, lb)
+    assert abs(na - nb) <= 1e-4 * na                  # the last step's gradient norm
+    for name, want in va.items():
+        d = np.abs(vb[name].astype(np.float64) - want)
+        assert d.max() <= 2.1 * 1e-3 * 5 and (d > 2e-5).mean() < 2e-3, name
+
+
 def test_loss_decreases_and_recall_rises(hip_lib, tmp_path):
     """Loss-curve smoke test: 60 steps on 512 synthetic records."""
     B, L = 64, 20
