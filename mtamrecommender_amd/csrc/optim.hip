@@ -335,17 +335,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
                                                    uint16_t *__restrict__ copy16, size_t copy_begin,
                                                    AdamImages wi) {
   __shared__ double dred[4];
-  float sc;
-  if (wi.norm_partials) {                      // launch-uniform
-    const float norm = sqrtf((float)block_sum_f64(wi.norm_partials, wi.n_norm, dred));
-    sc = wi.clip * fminf(1.0f / norm, 1.0f / wi.clip);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      wi.scale_out[0] = sc;
-      wi.scale_out[1] = norm;
+  float sc = 0.f;
+  // called by every thread of the workgroup AFTER its role has issued its own loads of p / m / v / g: the norm's
+  // partials are summed while those are in flight
+  auto clip_scale = [&]() {
+    if (wi.norm_partials) {                    // launch-uniform
+      const float norm = sqrtf((float)block_sum_f64(wi.norm_partials, wi.n_norm, dred));
+      sc = wi.clip * fminf(1.0f / norm, 1.0f / wi.clip);
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        wi.scale_out[0] = sc;
+        wi.scale_out[1] = norm;
+      }
+    } else {
+      sc = scale[0];
     }
-  } else {
-    sc = scale[0];
-  }
+  };
   const float lr_t = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   const size_t base = (size_t)blockIdx.x * NORM_BLOCK;
@@ -379,16 +383,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
     while (j + 1 < wi.n && blockIdx.x >= wi.n_linear + wi.first_block[j + 1]) ++j;
     const int K = wi.K[j], N = wi.N[j], n4 = N / 4;
     const size_t unit = (size_t)(blockIdx.x - wi.n_linear - wi.first_block[j]) * 256 + threadIdx.x;
-    if (unit >= (size_t)(K / 4) * n4) return;
+    const bool live = unit < (size_t)(K / 4) * n4;
     const int g4 = (int)(unit / n4), col = (int)(unit % n4) * 4;        // rows 4 g4 .. 4 g4 + 4
     const size_t e0 = wi.begin[j] + (size_t)g4 * 4 * N + col;
     adam_f4 pe[4], me[4], ve[4], ge[4];
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const size_t e = e0 + (size_t)i * N;
-      pe[i] = *reinterpret_cast<const adam_f4 *>(p + e); me[i] = *reinterpret_cast<const adam_f4 *>(m + e);
-      ve[i] = *reinterpret_cast<const adam_f4 *>(v + e); ge[i] = *reinterpret_cast<const adam_f4 *>(g + e);
+      for (int i = 0; i < 4; ++i) {
+        const size_t e = e0 + (size_t)i * N;
+        pe[i] = *reinterpret_cast<const adam_f4 *>(p + e); me[i] = *reinterpret_cast<const adam_f4 *>(m + e);
+        ve[i] = *reinterpret_cast<const adam_f4 *>(v + e); ge[i] = *reinterpret_cast<const adam_f4 *>(g + e);
+      }
     }
+    clip_scale();
+    if (!live) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -438,24 +446,37 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
     }
     return;
   }
+  // ---- linear sweep: all of the workgroup's 16-byte groups are fetched first, then the scale, then the updates
+  typedef float adam_f4 __attribute__((ext_vector_type(4)));
+  constexpr int NG = NORM_BLOCK / 1024;
+  adam_f4 pq[NG], mq[NG], vq[NG], gq[NG];
+  bool skip[NG];
 #pragma unroll
-  for (int i = 0; i < NORM_BLOCK / 1024; ++i) {
+  for (int i = 0; i < NG; ++i) {
     const size_t o = base + (size_t)(threadIdx.x + 256 * i) * 4;
     bool in_matrix = false;                    // (begin and size are multiples of 4: a group is inside or outside)
     for (int j = 0; j < wi.n; ++j) in_matrix |= o >= wi.begin[j] && o < wi.end[j];
-    if (in_matrix) continue;
-    if (o + 3 < n) {
-      typedef float adam_f4 __attribute__((ext_vector_type(4)));
-      adam_f4 pv, mv, vv, gv;
+    skip[i] = in_matrix;
+    if (!in_matrix && o + 3 < n) {
       if (NT) {        // streamed once per step: nothing of the seven streams is worth a cache line
-        pv = __builtin_nontemporal_load(reinterpret_cast<const adam_f4 *>(p + o));
-        mv = __builtin_nontemporal_load(reinterpret_cast<const adam_f4 *>(m + o));
-        vv = __builtin_nontemporal_load(reinterpret_cast<const adam_f4 *>(v + o));
-        gv = __builtin_nontemporal_load(reinterpret_cast<const adam_f4 *>(g + o));
+        pq[i] = __builtin_nontemporal_load(reinterpret_cast<const adam_f4 *>(p + o));
+        mq[i] = __builtin_nontemporal_load(reinterpret_cast<const adam_f4 *>(m + o));
+        vq[i] = __builtin_nontemporal_load(reinterpret_cast<const adam_f4 *>(v + o));
+        gq[i] = __builtin_nontemporal_load(reinterpret_cast<const adam_f4 *>(g + o));
       } else {
-        pv = *reinterpret_cast<const adam_f4 *>(p + o); mv = *reinterpret_cast<const adam_f4 *>(m + o);
-        vv = *reinterpret_cast<const adam_f4 *>(v + o); gv = *reinterpret_cast<const adam_f4 *>(g + o);
+        pq[i] = *reinterpret_cast<const adam_f4 *>(p + o); mq[i] = *reinterpret_cast<const adam_f4 *>(m + o);
+        vq[i] = *reinterpret_cast<const adam_f4 *>(v + o); gq[i] = *reinterpret_cast<const adam_f4 *>(g + o);
       }
+    }
+  }
+  clip_scale();
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const size_t o = base + (size_t)(threadIdx.x + 256 * i) * 4;
+    if (skip[i]) continue;
+    if (o + 3 < n) {
+      adam_f4 pv = pq[i], mv = mq[i], vv = vq[i];
+      const adam_f4 gv = gq[i];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float pe = pv[k], me = mv[k], ve = vv[k];
