@@ -234,6 +234,22 @@ constexpr int A3_PITCH = 2 * (2 * D) + 16;        // bytes per staged row of one
 constexpr int A3_IMG = ROWS * A3_PITCH;           // one image of the stripe
 constexpr int X3_PITCH = D + 4;                   // floats per staged x row
 
+// tools/chain_lab.hip (-DMTAM_CHAIN_STAMPS): s_memrealtime (100 MHz) at the phase boundaries of the two split-bf16
+// stripe kernels, wave 0 of the middle workgroup; the product build has none
+#ifdef MTAM_CHAIN_STAMPS
+__device__ unsigned long long g_chain_stamps[2][16];
+#define CH_STAMP(k, i)                                                                             \
+  if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    g_chain_stamps[k][i] = __builtin_amdgcn_s_memrealtime();                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  }
+#define CH_WAIT_VM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+#define CH_STAMP(k, i)
+#define CH_WAIT_VM
+#endif
+
 template <bool GATHER>
 __global__ __launch_bounds__(256) void seq_chain_x3_kernel(ChainArgs p) {
   // 50,688 B: the three images of the input stripe; once every wave is through the first product the same bytes
@@ -245,7 +261,60 @@ __global__ __launch_bounds__(256) void seq_chain_x3_kernel(ChainArgs p) {
   const long row0 = (long)blockIdx.x * ROWS;
   const int R = p.R;
 
-  // ---- stage 1 B operand: the three images of W4 columns 32 w + r, k = 16 s + 8 h .. + 8 (16 k-steps)
+  CH_STAMP(0, 0)
+  // The prologue's loads in the order their data is NEEDED -- a wave's loads complete in issue order (vmcnt), so a
+  // small dependent load issued behind 48 weight-fragment loads waits for all of them: ids (all of them) first; the
+  // looked-up rows as soon as the ids are here; then the first product's B operand (the three images of W4 columns
+  // 32 w + r, k = 16 s + 8 h .. + 8: 16 k-steps) and, behind it, this wave's first column block of the second stage,
+  // which lands while the first product runs.  tools/chain_lab.hip, middle workgroup of 200: in the order B operand,
+  // ids, rows the ids were back after 2.8 us and the first column block took 3.1 us behind its own fetch; now 1.0 and
+  // 1.9 us -- but a wave holds at most 64 loads in flight and one CU moves 64 B a clock, so the rows now wait while the
+  // 72 weight loads behind them are issued: 16.7 against 17.4 us per launch stand-alone (tools/chain_scale.py), the
+  // same 0.2347 ms per step -- not the 3 us the stamps promised.
+  const bool has_users = GATHER && (long)blockIdx.x * 32 < p.B;
+  const bool is_cat = (tid & 63) >= 32;
+  int id[8], pid[16], uid[4];
+  if (GATHER) {
+    const int32_t *ids = is_cat ? p.cat_ids : p.item_ids;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) id[i] = ids[min(row0 + 4 * i + w, (long)R - 1)];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pid[q] = p.pos_ids[min(row0 + (q & 3) + 8 * (q >> 2) + 4 * h, (long)R - 1)];
+    if (has_users) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) uid[i] = p.user_ids[min((int)blockIdx.x * 32 + 8 * i + (tid >> 5), p.B - 1)];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 v[8], urow[4];
+  float pv[16];
+  if (GATHER) {
+    const float *tab = is_cat ? p.cat_table : p.item_table;
+    const int nrows = is_cat ? p.cat_rows : p.item_rows, off = ((tid & 63) - (is_cat ? 32 : 0)) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4 *>(tab + (size_t)clamp_row(id[i], nrows) * D + off);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pv[q] = p.pos_table[(size_t)clamp_row(pid[q], p.pos_rows) * D + 32 * w + r];
+    if (has_users) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        urow[i] = *reinterpret_cast<const f32x4 *>(p.user_table + (size_t)clamp_row(uid[i], p.user_rows) * D + (tid & 31) * 4);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = i * 256 + tid;
+      const long row = min(row0 + (c >> 6), (long)R - 1);
+      v[i] = *reinterpret_cast<const f32x4 *>(p.ic + row * (2 * D) + (c & 63) * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const long row = min(row0 + (q & 3) + 8 * (q >> 2) + 4 * h, (long)R - 1);
+      pv[q] = p.pos[row * D + 32 * w + r];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  CH_STAMP(0, 1)        // ids in, rows requested
   Tri b1[16];
   {
     const uint16_t *base = p.img4 + ((size_t)h * D + 32 * w + r) * 8;
@@ -255,66 +324,56 @@ __global__ __launch_bounds__(256) void seq_chain_x3_kernel(ChainArgs p) {
       for (int t = 0; t < 3; ++t)
         b1[s].t[t] = *reinterpret_cast<const bf16x8 *>(base + (size_t)t * (2 * D * D) + (size_t)s * (2 * D * 8));
   }
+  const int nb_kv = p.n_kv / 32, nb = nb_kv + p.n_x / 32;
+  auto load_block = [&](int j, Tri (&bw)[8], float &bias) {
+    const bool is_kv = j < nb_kv;
+    const uint16_t *img = is_kv ? p.imgkv : p.imgx;
+    const int ldw = is_kv ? p.n_kv : p.n_x, col = 32 * (is_kv ? j : j - nb_kv) + r;
+    const uint16_t *base = img + ((size_t)h * ldw + col) * 8;
+    const size_t term = (size_t)D * ldw;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        bw[s].t[t] = *reinterpret_cast<const bf16x8 *>(base + t * term + (size_t)s * (2 * ldw * 8));
+    bias = (is_kv ? p.bkv : p.bx)[col];
+  };
+  Tri bwA[8], bwB[8];
+  float biasA = 0.f, biasB = 0.f;
+  if (w < nb) load_block(w, bwA, biasA);
+  __builtin_amdgcn_sched_barrier(0);
   float sq = 0.f;
-  {
-    f32x4 v[8];
-    if (GATHER) {
-      const bool is_cat = (tid & 63) >= 32;
-      const int32_t *ids = is_cat ? p.cat_ids : p.item_ids;
-      const float *tab = is_cat ? p.cat_table : p.item_table;
-      const int nrows = is_cat ? p.cat_rows : p.item_rows, off = ((tid & 63) - (is_cat ? 32 : 0)) * 4;
-      int id[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) id[i] = ids[min(row0 + 4 * i + w, (long)R - 1)];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4 *>(tab + (size_t)clamp_row(id[i], nrows) * D + off);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const long row = row0 + 4 * i + w;
-        if (row < R) {
-          sq += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
-          if (p.ic_out) *reinterpret_cast<f32x4 *>(p.ic_out + row * (2 * D) + (tid & 63) * 4) = v[i];
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = i * 256 + tid;
-        const long row = min(row0 + (c >> 6), (long)R - 1);
-        v[i] = *reinterpret_cast<const f32x4 *>(p.ic + row * (2 * D) + (c & 63) * 4);
-      }
-    }
-    // split on the way into LDS: four floats -> one 8-byte piece of each image (a wave writes 512 contiguous bytes)
+  if (GATHER) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int c = i * 256 + tid;
-      const float x4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-      bf16x4 q[3];
-      split_bf16::split4(x4, q);
-      unsigned char *dst = a_img + (c >> 6) * A3_PITCH + (c & 63) * 8;
-#pragma unroll
-      for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4 *>(dst + t * A3_IMG) = q[t];
+      const long row = row0 + 4 * i + w;
+      if (row < R) {
+        sq += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        if (p.ic_out) *reinterpret_cast<f32x4 *>(p.ic_out + row * (2 * D) + (tid & 63) * 4) = v[i];
+      }
     }
   }
-  float pv[16];
+  // split on the way into LDS: four floats -> one 8-byte piece of each image (a wave writes 512 contiguous bytes)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = i * 256 + tid;
+    const float x4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+    bf16x4 q[3];
+    split_bf16::split4(x4, q);
+    unsigned char *dst = a_img + (c >> 6) * A3_PITCH + (c & 63) * 8;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4 *>(dst + t * A3_IMG) = q[t];
+  }
+  CH_STAMP(0, 2)        // rows landed, split, written to LDS
   if (GATHER) {
-    int pid[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) pid[q] = p.pos_ids[min(row0 + (q & 3) + 8 * (q >> 2) + 4 * h, (long)R - 1)];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) pv[q] = p.pos_table[(size_t)clamp_row(pid[q], p.pos_rows) * D + 32 * w + r];
 #pragma unroll
     for (int q = 0; q < 16; ++q)
       if (row0 + (q & 3) + 8 * (q >> 2) + 4 * h < R) sq = fmaf(pv[q], pv[q], sq);
-    if ((long)blockIdx.x * 32 < p.B) {
-      int uid[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) uid[i] = p.user_ids[min((int)blockIdx.x * 32 + 8 * i + (tid >> 5), p.B - 1)];
+    if (has_users) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ub = blockIdx.x * 32 + 8 * i + (tid >> 5);
-        const f32x4 u = *reinterpret_cast<const f32x4 *>(p.user_table + (size_t)clamp_row(uid[i], p.user_rows) * D +
-                                                        (tid & 31) * 4);
+        const f32x4 u = urow[i];
         if (ub < p.B) {
           *reinterpret_cast<f32x4 *>(p.user_out + (size_t)ub * D + (tid & 31) * 4) = u;
           if (p.with_user) sq += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
@@ -328,14 +387,10 @@ __global__ __launch_bounds__(256) void seq_chain_x3_kernel(ChainArgs p) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (size_t i = g0; i < p.n_a4; i += stride) p.clear_a[i] = z;
     for (size_t i = g0; i < p.n_b4; i += stride) p.clear_b[i] = z;
-  } else {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const long row = min(row0 + (q & 3) + 8 * (q >> 2) + 4 * h, (long)R - 1);
-      pv[q] = p.pos[row * D + 32 * w + r];
-    }
   }
+  CH_STAMP(0, 3)        // position / user rows, clears
   __syncthreads();
+  CH_STAMP(0, 4)        // barrier 1
 
   // ---- z = ic . W4 (K = 256 = 16 k-steps of 16): two accumulator chains, six terms per step
   f32x16 zr16, x16;
@@ -359,11 +414,16 @@ __global__ __launch_bounds__(256) void seq_chain_x3_kernel(ChainArgs p) {
       zr16[q] = fmaxf(z[q], 0.f);
       x16[q] = zr16[q] + pv[q];
     }
+    CH_STAMP(0, 6)      // first product done
+    // (the first product's B operand is dead: the second column block's weights go out before the x stripe is written)
+    if (w + 4 < nb) load_block(w + 4, bwB, biasB);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                        // every wave has read its last fragment of the input images
 #pragma unroll
     for (int q = 0; q < 16; ++q) x_lds[((q & 3) + 8 * (q >> 2) + 4 * h) * X3_PITCH + col] = x16[q];
   }
   __syncthreads();
+  CH_STAMP(0, 7)        // x in LDS
   float *scratch = x_lds + ROWS * X3_PITCH + w * (ROWS * T_PITCH);
   store_tile(scratch, zr16, p.zr, row0, R, D, 32 * w, lane);
   store_tile(scratch, x16, p.x, row0, R, D, 32 * w, lane);
@@ -380,20 +440,7 @@ __global__ __launch_bounds__(256) void seq_chain_x3_kernel(ChainArgs p) {
       af[s] = split_bf16::split8(x8);
     }
   }
-  const int nb_kv = p.n_kv / 32, nb = nb_kv + p.n_x / 32;
-  auto load_block = [&](int j, Tri (&bw)[8], float &bias) {
-    const bool is_kv = j < nb_kv;
-    const uint16_t *img = is_kv ? p.imgkv : p.imgx;
-    const int ldw = is_kv ? p.n_kv : p.n_x, col = 32 * (is_kv ? j : j - nb_kv) + r;
-    const uint16_t *base = img + ((size_t)h * ldw + col) * 8;
-    const size_t term = (size_t)D * ldw;
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-        bw[s].t[t] = *reinterpret_cast<const bf16x8 *>(base + t * term + (size_t)s * (2 * ldw * 8));
-    bias = (is_kv ? p.bkv : p.bx)[col];
-  };
+  CH_STAMP(0, 8)        // zr, x stored; A fragments split
   auto run_block = [&](int j, const Tri (&bw)[8], float bias) {
     f32x16 a0 = {0.f}, a1 = {0.f};
 #pragma unroll
@@ -410,17 +457,18 @@ __global__ __launch_bounds__(256) void seq_chain_x3_kernel(ChainArgs p) {
     }
     store_tile(scratch, o, out, row0, R, ldo, col - r, lane);
   };
-  Tri bwA[8], bwB[8];
-  float biasA = 0.f, biasB = 0.f;
-  if (w < nb) load_block(w, bwA, biasA);
   for (int j = w; j < nb; j += 8) {
-    if (j + 4 < nb) load_block(j + 4, bwB, biasB);
     run_block(j, bwA, biasA);
+    CH_STAMP(0, 9 + (j >> 2))        // a column block done (9, 11, ..)
+    if (j + 8 < nb) load_block(j + 8, bwA, biasA);
     if (j + 4 < nb) {
-      if (j + 8 < nb) load_block(j + 8, bwA, biasA);
       run_block(j + 4, bwB, biasB);
+      CH_STAMP(0, 10 + (j >> 2))     // (10, 12, ..)
+      if (j + 12 < nb) load_block(j + 12, bwB, biasB);
     }
   }
+  CH_WAIT_VM
+  CH_STAMP(0, 15)       // stores drained
 }
 
 // ---------------------------------------------------------------------------------------------------------------
