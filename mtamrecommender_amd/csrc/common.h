@@ -45,6 +45,50 @@ __device__ __forceinline__ float group_sum(float v, int width) {
   return v;
 }
 
+// The same sums on the VALU's data-parallel primitives: __shfl_xor compiles to ds_bpermute_b32 -- an address register
+// and a trip through the LDS crossbar per step (132 of them in the decoder's forward kernel, 5.2 of its 11.6 us in the
+// per-key score phase, tools/attn_lab.hip) -- while a DPP operand comes from another lane of the same 16-lane row at
+// register speed: quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror, then ds_swizzle (xor 16 inside a half
+// wave) and one __shfl_xor for the wave's two halves.  Every lane of the group ends with the group's sum; the order
+// of the additions differs from group_sum's (fp32 rounding).  All lanes of the group must be active.
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float swizzle_xor16(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+template <int WIDTH> __device__ __forceinline__ float group_sum_dpp(float v) {
+  static_assert(WIDTH == 2 || WIDTH == 4 || WIDTH == 8 || WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "power of two");
+  if (WIDTH >= 2) v += dpp_f32<0xB1>(v);
+  if (WIDTH >= 4) v += dpp_f32<0x4E>(v);
+  if (WIDTH >= 8) v += dpp_f32<0x141>(v);
+  if (WIDTH >= 16) v += dpp_f32<0x140>(v);
+  if (WIDTH >= 32) v += swizzle_xor16(v);
+  if (WIDTH >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+template <int WIDTH> __device__ __forceinline__ float group_max_dpp(float v) {
+  if (WIDTH >= 2) v = fmaxf(v, dpp_f32<0xB1>(v));
+  if (WIDTH >= 4) v = fmaxf(v, dpp_f32<0x4E>(v));
+  if (WIDTH >= 8) v = fmaxf(v, dpp_f32<0x141>(v));
+  if (WIDTH >= 16) v = fmaxf(v, dpp_f32<0x140>(v));
+  if (WIDTH >= 32) v = fmaxf(v, swizzle_xor16(v));
+  if (WIDTH >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+// width: a power of two, wave-uniform
+__device__ __forceinline__ float group_sum_fast(float v, int width) {
+  switch (width) {
+    case 32: return group_sum_dpp<32>(v);
+    case 16: return group_sum_dpp<16>(v);
+    case 8: return group_sum_dpp<8>(v);
+    case 4: return group_sum_dpp<4>(v);
+    case 2: return group_sum_dpp<2>(v);
+    case 64: return group_sum_dpp<64>(v);
+    default: return v;
+  }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // Hardware-transcendental forms for the serial GRU / attention steps, where the accurate libm

@@ -11,6 +11,20 @@
 //   wavefront-reduced masked softmax per head, weighted V sum, residual, LN.
 #include "common.h"
 
+// tools/attn_lab.hip (-DMTAM_ATTN_STAMPS): s_memrealtime (100 MHz) at the phase boundaries of the two decoder kernels,
+// thread 0 of the middle workgroup; the product build has none
+#ifdef MTAM_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[2][16];
+#define AT_STAMP(k, i)                                                                             \
+  if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) {                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    g_attn_stamps[k][i] = __builtin_amdgcn_s_memrealtime();                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  }
+#else
+#define AT_STAMP(k, i)
+#endif
+
 namespace {
 
 constexpr int D = MTAM_D;
@@ -60,6 +74,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
   // barrier: the sample's key / raw-key / value rows (half a wave per row, rows hw, hw+8, ... of the
   // sample), the key times and time-gate parameters, and the LN parameters.  The kernel is a chain of
   // short phases on one CU; written phase by phase it paid one global round trip per phase (~9 of them).
+  AT_STAMP(0, 0)
   const int hw = tid >> 5, li = tid & 31;
   constexpr int KB = 8;                      // keys per half wave and trip: 64 keys per trip of the workgroup
   const float q_in = (tid < D) ? p.dec_in[(size_t)b * D + tid] : 0.f;
@@ -80,8 +95,10 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
     }
   };
   load_keys(hw);
+  AT_STAMP(0, 1)       // argument-only loads issued
   if (tid < D) q_s[tid] = q_in;
   __syncthreads();
+  AT_STAMP(0, 2)       // q in LDS
 
   // [Q | qt] = q . [Wq | Wt]; thread = output column, coalesced weight reads, 16 loads in flight
   {
@@ -103,6 +120,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
     else qt_s[tid - D] = acc;
   }
   __syncthreads();
+  AT_STAMP(0, 3)       // [Q | qt] projected
 
   // scores, masked softmax and the weighted value sum, 64 keys per trip (one trip for L <= 64).  The
   // value rows stay in registers from the load above until the softmax weights exist; for L > 64 the
@@ -115,8 +133,8 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
       const int j = jb + 8 * i;
       if (j >= L) break;
       if (j < sl) {
-        const float dK = group_sum(dot4(kq[i], Q4), lanes_per_head);
-        const float dA = group_sum(dot4(xq[i], T4), 32);
+        const float dK = group_sum_fast(dot4(kq[i], Q4), lanes_per_head);
+        const float dA = group_sum_dpp<32>(dot4(xq[i], T4));
         const float a = fast_tanh(dA);
         const float delta = logf(fabsf(tq - tk[i]) + 1.0f);
         const float dk = fast_tanh(delta * tp[i][0] + tp[i][1]);
@@ -140,22 +158,24 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
     score_keys(jb);
   }
   __syncthreads();
+  AT_STAMP(0, 4)       // scores
 
   // masked softmax over keys, one wave per head
   for (int h = w; h < H; h += 4) {
     float m = -INFINITY;
     for (int j = lane; j < L; j += 64) m = fmaxf(m, sc_s[h][j]);
-    m = wave_max(m);
+    m = group_max_dpp<64>(m);
     float s = 0.f;
     for (int j = lane; j < L; j += 64) {
       const float e = fast_exp(sc_s[h][j] - m);
       sc_s[h][j] = e;
       s += e;
     }
-    s = wave_sum(s);
+    s = group_sum_dpp<64>(s);
     for (int j = lane; j < L; j += 64) sc_s[h][j] = sc_s[h][j] / s;
   }
   __syncthreads();
+  AT_STAMP(0, 5)       // softmax
 
   // O = W . V: each half wave sums its own keys (4 channels per lane), the 8 partial rows meet in LDS
   {
@@ -181,13 +201,14 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
     *reinterpret_cast<float4 *>(&o_part[hw][4 * li]) = o;
   }
   __syncthreads();
+  AT_STAMP(0, 6)       // weighted values
 
   // residual + normalize(eps = 1e-8): (y - mean) / sqrt(var + eps) * gamma + beta
   float y = 0.f;
   if (tid < D) {
     y = ((o_part[0][tid] + o_part[1][tid]) + (o_part[2][tid] + o_part[3][tid])) +
         ((o_part[4][tid] + o_part[5][tid]) + (o_part[6][tid] + o_part[7][tid])) + q_s[tid];
-    const float s = wave_sum(y);
+    const float s = group_sum_dpp<64>(y);
     if (lane == 0) red[w] = s;
   }
   __syncthreads();
@@ -195,7 +216,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
   if (tid < D) {
     const float mean = (red[0] + red[1]) / (float)D;
     diff = y - mean;
-    const float s = wave_sum(diff * diff);
+    const float s = group_sum_dpp<64>(diff * diff);
     if (lane == 0) red[2 + w] = s;
   }
   __syncthreads();
@@ -227,10 +248,11 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
       sv[3 * L + H * L + i] = sc_s[h][j];
     }
   }
+  AT_STAMP(0, 7)       // normalize, saves issued
   if (p.pred_out) {                    // block-uniform: fused head layer_norm
     __syncthreads();                   // red[] is reused
     if (tid < D) {
-      const float s1 = wave_sum(out);
+      const float s1 = group_sum_dpp<64>(out);
       if (lane == 0) red[w] = s1;
     }
     __syncthreads();
@@ -238,7 +260,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
     if (tid < D) {
       mean2 = (red[0] + red[1]) / (float)D;
       d2 = out - mean2;
-      const float s2 = wave_sum(d2 * d2);
+      const float s2 = group_sum_dpp<64>(d2 * d2);
       if (lane == 0) red[2 + w] = s2;
     }
     __syncthreads();
@@ -253,6 +275,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
       }
     }
   }
+  AT_STAMP(0, 8)       // head layer_norm
 }
 
 struct BwdArgs {
@@ -332,7 +355,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
       a = yp * p.head_gamma[tid];
       p.d_head_partial[((size_t)b * 2 + 0) * D + tid] = yp;
       p.d_head_partial[((size_t)b * 2 + 1) * D + tid] = yp * hh;
-      const float s1 = wave_sum(a), s2 = wave_sum(a * hh);
+      const float s1 = group_sum_dpp<64>(a), s2 = group_sum_dpp<64>(a * hh);
       if (lane == 0) { red[w] = s1; red[2 + w] = s2; }
     }
     __syncthreads();
@@ -350,7 +373,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     p.d_ln_partial[((size_t)b * 2 + 0) * D + tid] = dy;
     p.d_ln_partial[((size_t)b * 2 + 1) * D + tid] = dy * xhat;
     dxh = dy * p.ln_gamma[tid];
-    const float s1 = wave_sum(dxh), s2 = wave_sum(dxh * xhat);
+    const float s1 = group_sum_dpp<64>(dxh), s2 = group_sum_dpp<64>(dxh * xhat);
     if (lane == 0) { red[w] = s1; red[2 + w] = s2; }
     Q_s[tid] = sv[tid];
     qt_s[tid] = sv[D + tid];
@@ -378,7 +401,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
         const int j = jb + 8 * i;
         if (j >= L) break;
         if (j < sl) {
-          const float dW = group_sum(dot4(vq[i], dO4), lanes_per_head);
+          const float dW = group_sum_fast(dot4(vq[i], dO4), lanes_per_head);
           if ((li % lanes_per_head) == 0) ds_s[head_of_lane][j] = dW;
         } else if (li < H) {
           ds_s[li][j] = 0.f;
@@ -391,7 +414,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
   for (int h = w; h < H; h += 4) {
     float s = 0.f;
     for (int j = lane; j < sl; j += 64) s += w_s[h][j] * ds_s[h][j];
-    s = wave_sum(s);
+    s = group_sum_dpp<64>(s);
     for (int j = lane; j < L; j += 64) ds_s[h][j] = (j < sl) ? w_s[h][j] * (ds_s[h][j] - s) : 0.f;
   }
   __syncthreads();
@@ -486,7 +509,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[i] = dqp_s[lane + 64 * i];
     // the wave's 32 weight rows (128 loads) are all in flight before the first one is reduced; the
-    // 32 wave sums run as four batches of eight independent shuffle chains
+    // 32 wave sums run as four batches of eight independent chains (DPP adds inside the 16-lane rows)
     float wv[32][4];
 #pragma unroll
     for (int r = 0; r < 32; ++r)
@@ -503,9 +526,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
         sv8[r] = s;
       }
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) sv8[r] += __shfl_xor(sv8[r], off, 64);
+      for (int r = 0; r < 8; ++r) sv8[r] = group_sum_dpp<64>(sv8[r]);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int c = w + 4 * (r0 + r);
