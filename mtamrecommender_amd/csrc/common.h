@@ -29,16 +29,6 @@ void mtam_set_error(const char *fmt, ...);
 static inline bool mtam_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- wave64 reductions (all 64 lanes get the result) -----------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
-}
 // reduce inside aligned groups of `width` lanes (width a power of two <= 64)
 __device__ __forceinline__ float group_sum(float v, int width) {
   for (int off = width >> 1; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -76,6 +66,9 @@ template <int WIDTH> __device__ __forceinline__ float group_max_dpp(float v) {
   if (WIDTH >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
+// the whole wave (every lane active): all 64 lanes end with the result
+__device__ __forceinline__ float wave_sum(float v) { return group_sum_dpp<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return group_max_dpp<64>(v); }
 // width: a power of two, wave-uniform
 __device__ __forceinline__ float group_sum_fast(float v, int width) {
   switch (width) {
