@@ -66,6 +66,26 @@ template <int WIDTH> __device__ __forceinline__ float group_max_dpp(float v) {
   if (WIDTH >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, CTRL, 0xf, 0xf, true);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_ds_swizzle((int)(unsigned int)u, 0x401F);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_ds_swizzle((int)(unsigned int)(u >> 32), 0x401F);
+    v += __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+  }
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
 // the whole wave (every lane active): all 64 lanes end with the result
 __device__ __forceinline__ float wave_sum(float v) { return group_sum_dpp<64>(v); }
 __device__ __forceinline__ float wave_max(float v) { return group_max_dpp<64>(v); }

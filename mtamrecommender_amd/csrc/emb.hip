@@ -190,8 +190,7 @@ __device__ __forceinline__ double rider_sum_f64(const float *__restrict__ src, i
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc += (base + (int)threadIdx.x + SCATTER_THREADS * q < n) ? (double)v[q] : 0.0;
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  acc = wave_sum_f64(acc);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = acc;
   __syncthreads();

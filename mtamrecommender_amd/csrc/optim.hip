@@ -40,8 +40,7 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(const float *__restrict
   __shared__ double red[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  s = wave_sum_f64(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -67,8 +66,7 @@ __global__ __launch_bounds__(256) void partials_sum_kernel(const float *__restri
   __shared__ double red[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  s = wave_sum_f64(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -182,8 +180,7 @@ __global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restric
     a_l2 = sum_plain(l2_partial, n_l2);
     c_ce = sum_plain(ce, B);
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+  t = wave_sum_f64(t);
   if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = t;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -203,11 +200,8 @@ __global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restric
     // step epilogue: the reported loss (Model/base_model.py:322-326) from the per-row cross entropies
     // and the gather's L2 partials -- both written by earlier kernels of the step
     double a = a_l2, c = c_ce;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      a += __shfl_xor(a, off, 64);
-      c += __shfl_xor(c, off, 64);
-    }
+    a = wave_sum_f64(a);
+    c = wave_sum_f64(c);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = a;
     __syncthreads();
@@ -235,8 +229,7 @@ __device__ __forceinline__ double block_sum_f64(const float *__restrict__ src, i
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc += (base + (int)threadIdx.x + 256 * q < n) ? (double)v[q] : 0.0;
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  acc = wave_sum_f64(acc);
   if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = acc;
   __syncthreads();
   const double t = (dred[0] + dred[1]) + (dred[2] + dred[3]);
