@@ -38,14 +38,21 @@ __device__ __forceinline__ float group_sum(float v, int width) {
 // The same sums on the VALU's data-parallel primitives: __shfl_xor compiles to ds_bpermute_b32 -- an address register
 // and a trip through the LDS crossbar per step (132 of them in the decoder's forward kernel, 5.2 of its 11.6 us in the
 // per-key score phase, tools/attn_lab.hip) -- while a DPP operand comes from another lane of the same 16-lane row at
-// register speed: quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror, then ds_swizzle (xor 16 inside a half
-// wave) and one __shfl_xor for the wave's two halves.  Every lane of the group ends with the group's sum; the order
+// register speed: quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror, then the row / half-wave swaps below.  Every lane of the group ends with the group's sum; the order
 // of the additions differs from group_sum's (fp32 rounding).  All lanes of the group must be active.
 template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float swizzle_xor16(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+// across the rows: v_permlane16_swap / v_permlane32_swap (gfx950) exchange the odd 16-lane rows of one register with
+// the even rows of another (the upper half wave with the lower): fed the same value twice they return (row 0, row 0,
+// row 2, row 2) and (row 1, row 1, row 3, row 3) -- the two operands of the xor-16 (xor-32) step, on the VALU
+__device__ __forceinline__ void rows_xor16(unsigned int u, unsigned int &a, unsigned int &b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void halves_xor32(unsigned int u, unsigned int &a, unsigned int &b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  a = r[0]; b = r[1];
 }
 template <int WIDTH> __device__ __forceinline__ float group_sum_dpp(float v) {
   static_assert(WIDTH == 2 || WIDTH == 4 || WIDTH == 8 || WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "power of two");
@@ -53,8 +60,16 @@ template <int WIDTH> __device__ __forceinline__ float group_sum_dpp(float v) {
   if (WIDTH >= 4) v += dpp_f32<0x4E>(v);
   if (WIDTH >= 8) v += dpp_f32<0x141>(v);
   if (WIDTH >= 16) v += dpp_f32<0x140>(v);
-  if (WIDTH >= 32) v += swizzle_xor16(v);
-  if (WIDTH >= 64) v += __shfl_xor(v, 32, 64);
+  if (WIDTH >= 32) {
+    unsigned int a, b;
+    rows_xor16(__builtin_bit_cast(unsigned int, v), a, b);
+    v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+  }
+  if (WIDTH >= 64) {
+    unsigned int a, b;
+    halves_xor32(__builtin_bit_cast(unsigned int, v), a, b);
+    v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+  }
   return v;
 }
 template <int WIDTH> __device__ __forceinline__ float group_max_dpp(float v) {
@@ -62,8 +77,16 @@ template <int WIDTH> __device__ __forceinline__ float group_max_dpp(float v) {
   if (WIDTH >= 4) v = fmaxf(v, dpp_f32<0x4E>(v));
   if (WIDTH >= 8) v = fmaxf(v, dpp_f32<0x141>(v));
   if (WIDTH >= 16) v = fmaxf(v, dpp_f32<0x140>(v));
-  if (WIDTH >= 32) v = fmaxf(v, swizzle_xor16(v));
-  if (WIDTH >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+  if (WIDTH >= 32) {
+    unsigned int a, b;
+    rows_xor16(__builtin_bit_cast(unsigned int, v), a, b);
+    v = fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+  }
+  if (WIDTH >= 64) {
+    unsigned int a, b;
+    halves_xor32(__builtin_bit_cast(unsigned int, v), a, b);
+    v = fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+  }
   return v;
 }
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
@@ -79,11 +102,20 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   v += dpp_f64<0x140>(v);
   {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_ds_swizzle((int)(unsigned int)u, 0x401F);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_ds_swizzle((int)(unsigned int)(u >> 32), 0x401F);
-    v += __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+    unsigned int la, lb, ha, hb;
+    rows_xor16((unsigned int)u, la, lb);
+    rows_xor16((unsigned int)(u >> 32), ha, hb);
+    v = __builtin_bit_cast(double, (unsigned long long)la | ((unsigned long long)ha << 32)) +
+        __builtin_bit_cast(double, (unsigned long long)lb | ((unsigned long long)hb << 32));
   }
-  v += __shfl_xor(v, 32, 64);
+  {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    unsigned int la, lb, ha, hb;
+    halves_xor32((unsigned int)u, la, lb);
+    halves_xor32((unsigned int)(u >> 32), ha, hb);
+    v = __builtin_bit_cast(double, (unsigned long long)la | ((unsigned long long)ha << 32)) +
+        __builtin_bit_cast(double, (unsigned long long)lb | ((unsigned long long)hb << 32));
+  }
   return v;
 }
 // the whole wave (every lane active): all 64 lanes end with the result
