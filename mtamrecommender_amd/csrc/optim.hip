@@ -222,12 +222,13 @@ __global__ __launch_bounds__(256) void sqnorm_clip_kernel(const float *__restric
 // in batches of eight loads (clamped index, masked value), wave shuffle, four waves through LDS
 __device__ __forceinline__ double block_sum_f64(const float *__restrict__ src, int n, double (&dred)[4]) {
   double acc = 0.0;
-  for (int base = 0; base < n; base += 256 * 8) {
-    float v[8];
+  // (24 loads in flight per thread and trip -- 6,144 values, the whole list at ml-1m sizes -- added in index order)
+  for (int base = 0; base < n; base += 256 * 24) {
+    float v[24];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = src[min(base + (int)threadIdx.x + 256 * q, n - 1)];
+    for (int q = 0; q < 24; ++q) v[q] = src[min(base + (int)threadIdx.x + 256 * q, n - 1)];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc += (base + (int)threadIdx.x + 256 * q < n) ? (double)v[q] : 0.0;
+    for (int q = 0; q < 24; ++q) acc += (base + (int)threadIdx.x + 256 * q < n) ? (double)v[q] : 0.0;
   }
   acc = wave_sum_f64(acc);
   if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = acc;
