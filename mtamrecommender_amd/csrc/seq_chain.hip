@@ -531,10 +531,13 @@ __global__ __launch_bounds__(256) void seq_chain_bwd_kernel(ChainBwdArgs p) {
     // every load first (20 sixteen-byte pieces per thread at K1 = 640), then the splits and the LDS writes
     const int p4 = K1 / 4, nx4 = p.n_x / 4, total = ROWS * p4;
     constexpr int NP = ROWS * (BWD_MAX_K / 4) / 256;
+    // id / p4 by a multiply and a shift, exact for id < 32 p4 <= 5,120 (id p4 < 2^20): a division by a run-time value is
+    // ~25 VALU instructions, and there were 60 of them per thread in this prologue
+    const unsigned inv_p4 = (1u << 20) / (unsigned)p4 + 1u;
     f32x4 v[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int id = min(i * 256 + tid, total - 1), row = id / p4, c4 = id % p4;
+      const int id = min(i * 256 + tid, total - 1), row = (int)(((unsigned)id * inv_p4) >> 20), c4 = id - row * p4;
       const long gr = min(row0 + row, (long)R - 1);
       v[i] = c4 < nx4 ? *reinterpret_cast<const f32x4 *>(p.d_xproj + gr * p.n_x + c4 * 4)
                       : *reinterpret_cast<const f32x4 *>(p.d_kv + gr * p.n_kv + (c4 - nx4) * 4);
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(256) void seq_chain_bwd_kernel(ChainBwdArgs p) {
     for (int i = 0; i < NP; ++i) {
       const int id = i * 256 + tid;
       if (id < total) {
-        const int row = id / p4, c4 = id % p4;
+        const int row = (int)(((unsigned)id * inv_p4) >> 20), c4 = id - row * p4;
         const float x4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
         bf16x4 q[3];
         split_bf16::split4(x4, q);
