@@ -376,9 +376,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
     int j = 0;
     while (j + 1 < wi.n && blockIdx.x >= wi.n_linear + wi.first_block[j + 1]) ++j;
     const int K = wi.K[j], N = wi.N[j], n4 = N / 4;
-    const size_t unit = (size_t)(blockIdx.x - wi.n_linear - wi.first_block[j]) * 256 + threadIdx.x;
-    const bool live = unit < (size_t)(K / 4) * n4;
-    const int g4 = (int)(unit / n4), col = (int)(unit % n4) * 4;        // rows 4 g4 .. 4 g4 + 4
+    // (32-bit: a 64-bit division by a run-time value is over a hundred instructions)
+    const unsigned unit = (blockIdx.x - wi.n_linear - wi.first_block[j]) * 256u + threadIdx.x;
+    const bool live = unit < (unsigned)(K / 4) * (unsigned)n4;
+    const int g4 = (int)(unit / (unsigned)n4), col = (int)(unit - (unsigned)g4 * (unsigned)n4) * 4;   // rows 4 g4 .. 4 g4 + 4
     const size_t e0 = wi.begin[j] + (size_t)g4 * 4 * N + col;
     adam_f4 pe[4], me[4], ve[4], ge[4];
     if (live) {
