@@ -66,9 +66,11 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int L = p.L, H = p.H;
   const int sl = min(max(p.seq_len[b], 0), L);
+  const unsigned inv_L = (1u << 20) / (unsigned)L + 1u;      // i / L for i < H L <= 2,048 (i L < 2^20): exact
   const size_t row0 = (size_t)b * L;
-  const int lanes_per_head = 32 / H;
-  const float inv_div = sqrtf((float)(D / H));
+  // H is 1, 2, 4 or 8 (checked by the host): shifts and masks, not run-time divisions (~25 instructions each)
+  const int log_h = (H >= 2) + (H >= 4) + (H >= 8), lph_shift = 5 - log_h, lanes_per_head = 1 << lph_shift;
+  const float inv_div = sqrtf((float)(D >> log_h));
 
   // Every global load that does not depend on the projected query is issued HERE, before the first
   // barrier: the sample's key / raw-key / value rows (half a wave per row, rows hw, hw+8, ... of the
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
         const float dk = fast_tanh(delta * tp[i][0] + tp[i][1]);
         const float g = tp[i][2] * dk + tp[i][3] * a + tp[i][4];
         const float sg = fast_sigmoid(g);
-        if ((li % lanes_per_head) == 0) {
-          const int h = li / lanes_per_head;
+        if ((li & (lanes_per_head - 1)) == 0) {
+          const int h = li >> lph_shift;
           qk_s[h][j] = dK;
           sc_s[h][j] = (dK * sg) / inv_div;
         }
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
 
   // O = W . V: each half wave sums its own keys (4 channels per lane), the 8 partial rows meet in LDS
   {
-    const int head_of_lane = li / lanes_per_head;
+    const int head_of_lane = li >> lph_shift;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     auto add_values = [&](int jb) {
 #pragma unroll
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
       sv[2 * L + j] = sg_s[j];
     }
     for (int i = tid; i < H * L; i += 256) {
-      const int h = i / L, j = i - h * L;
+      const int h = (int)(((unsigned)i * inv_L) >> 20), j = i - h * L;
       sv[3 * L + i] = qk_s[h][j];
       sv[3 * L + H * L + i] = sc_s[h][j];
     }
@@ -307,9 +309,11 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int L = p.L, H = p.H;
   const int sl = min(max(p.seq_len[b], 0), L);
+  const unsigned inv_L = (1u << 20) / (unsigned)L + 1u;      // i / L for i < H L <= 2,048 (i L < 2^20): exact
   const size_t row0 = (size_t)b * L;
-  const int lanes_per_head = 32 / H;
-  const float inv_div = sqrtf((float)(D / H));
+  // H is 1, 2, 4 or 8 (checked by the host): shifts and masks, not run-time divisions (~25 instructions each)
+  const int log_h = (H >= 2) + (H >= 4) + (H >= 8), lph_shift = 5 - log_h, lanes_per_head = 1 << lph_shift;
+  const float inv_div = sqrtf((float)(D >> log_h));
   const float *sv = p.save + (size_t)b * save_floats(L, H);
   const float *sv_a = sv + 3 * D, *sv_dk = sv_a + L, *sv_sg = sv_dk + L;
   const float *sv_qk = sv_sg + L, *sv_w = sv_qk + H * L;
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
   // before the first barrier: the sample's key / value / raw-key rows (and the running d_x rows when
   // accumulating), half a wave per row, and each key's gate inputs (thread j = key j).
   const int hw = tid >> 5, li = tid & 31;
-  const int head_of_lane = li / lanes_per_head;
+  const int head_of_lane = li >> lph_shift;
   constexpr int KB = 8;
   float4 kq[KB], vq[KB], xq[KB], ox[KB];
   auto load_rows = [&](int jb) {
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     qt_s[tid] = sv[D + tid];
   }
   for (int i = tid; i < H * L; i += 256) {
-    const int h = i / L, j = i - h * L;
+    const int h = (int)(((unsigned)i * inv_L) >> 20), j = i - h * L;
     w_s[h][j] = sv_w[i];
   }
   __syncthreads();
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
         if (j >= L) break;
         if (j < sl) {
           const float dW = group_sum_fast(dot4(vq[i], dO4), lanes_per_head);
-          if ((li % lanes_per_head) == 0) ds_s[head_of_lane][j] = dW;
+          if ((li & (lanes_per_head - 1)) == 0) ds_s[head_of_lane][j] = dW;
         } else if (li < H) {
           ds_s[li][j] = 0.f;
         }
