@@ -774,6 +774,8 @@ struct SmallArgs {
   float *ms;                   // [2][G][128] (max, sum-exp) pairs
   float *dp_part;              // [2][G][128][128] shares of d_pred
   float *lse, *ce, *d_pred, *dE, *sq_partial;
+  int red_U, red_groups;       // the d_pred reduction's split: pieces per workgroup, groups of threads per piece
+  unsigned int red_inv_U;      // 2^20 / red_U + 1
 };
 
 // (a VMEM store of more than 8 bytes must not be followed at once by a VALU write of its data registers: the
@@ -861,10 +863,12 @@ __device__ __forceinline__ void small_fold_pairs(const float *ms, int G, int tid
 // pieces of the shares until all of them have been published.
 __device__ __forceinline__ void small_reduce_d_pred(const SmallArgs &p, const float *dp_part, int G, int c, int tid,
                                                     f32x4 *red) {
+  // (U, groups and 2^20 / U + 1 come from the host: a division by a run-time value is ~25 VALU instructions, and this
+  // is the launch's last dependent phase)
   const int units = p.Bt * (D / 4);                 // 16-byte pieces of d_pred
-  const int U = (units + G - 1) / G;                // <= 512 (G >= 8)
-  const int groups = min(768 / U, G);
-  const int ul = tid % U, grp = tid / U;
+  const int U = p.red_U;                            // ceil(units / G) <= 512 (G >= 8)
+  const int groups = p.red_groups;                  // min(768 / U, G)
+  const int grp = (int)(((unsigned)tid * p.red_inv_U) >> 20), ul = tid - grp * U;      // exact: tid U < 2^20
   const int unit = c * U + ul;
   if (grp < groups) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -1352,7 +1356,10 @@ extern "C" int mtam_score32_train(const float *E, const float *pred, const int32
   const int G = slabs_of(V);
   x3::SmallArgs a{E, pred, target, V, B, scale,
                   reinterpret_cast<unsigned int *>(work), work + x3::SMALL_HEAD_WORDS,
-                  work + x3::SMALL_HEAD_WORDS + 2 * (long)G * BT * 2, lse, ce, d_pred, dE, sq_partial};
+                  work + x3::SMALL_HEAD_WORDS + 2 * (long)G * BT * 2, lse, ce, d_pred, dE, sq_partial, 0, 0, 0u};
+  a.red_U = (B * (D / 4) + G - 1) / G;
+  a.red_groups = min(768 / a.red_U, G);
+  a.red_inv_U = (1u << 20) / (unsigned)a.red_U + 1u;
   hipLaunchKernelGGL(x3::train_small_kernel, dim3(G), dim3(768), x3::SMALL_LDS, static_cast<hipStream_t>(stream), a);
   MTAM_CHECK_LAUNCH("score32_train");
   return MTAM_OK;
