@@ -340,7 +340,9 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
         ox[i] = *reinterpret_cast<const float4 *>(&p.d_x[(row0 + min(jb + 8 * i, L - 1)) * D + 4 * li]);
     }
   };
+  AT_STAMP(1, 0)
   load_rows(hw);
+  AT_STAMP(1, 1)       // row loads issued
   const int jg = min(tid, L - 1);      // gate inputs of key `tid` (keys >= 256 are reloaded in the loop below)
   const float g_sg = sv_sg[jg], g_a = sv_a[jg], g_dk = sv_dk[jg];
   const float g_tk = p.t_keys[row0 + jg], g_tq = p.t_query[b];
@@ -369,6 +371,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     }
     __syncthreads();                   // red[] is reused below
   }
+  AT_STAMP(1, 2)       // head layer_norm backward
   // ---- normalize() backward
   float dxh = 0.f, xhat = 0.f;
   if (tid < D) {
@@ -395,6 +398,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
   }
   __syncthreads();
 
+  AT_STAMP(1, 3)       // normalize backward, dO in LDS
   // ---- dW[h][j] = dO_h . V_j   (64 keys per trip; one trip for L <= 64, its rows are already here)
   {
     const float4 dO4 = *reinterpret_cast<const float4 *>(&dO_s[4 * li]);
@@ -414,6 +418,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     }
   }
   __syncthreads();
+  AT_STAMP(1, 4)       // dW
   // ---- softmax backward: dS = W * (dW - sum_j W dW)
   for (int h = w; h < H; h += 4) {
     float s = 0.f;
@@ -422,6 +427,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     for (int j = lane; j < L; j += 64) ds_s[h][j] = (j < sl) ? w_s[h][j] * (ds_s[h][j] - s) : 0.f;
   }
   __syncthreads();
+  AT_STAMP(1, 5)       // softmax backward
   // ---- gate backward, thread per key
   for (int j = tid; j < L; j += 256) {
     float g_w1 = 0.f, g_b1 = 0.f, g_ow1 = 0.f, g_ow2 = 0.f, g_ob = 0.f, dap = 0.f;
@@ -453,6 +459,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     gp[0] = g_w1; gp[L] = g_b1; gp[2 * L] = g_ow1; gp[3 * L] = g_ow2; gp[4 * L] = g_ob;
   }
   __syncthreads();
+  AT_STAMP(1, 6)       // gate backward
   // ---- per key: dK, dV (relu-masked), raw-key gradient; accumulate dQ, d(qt)
   {
     const float4 dO4 = *reinterpret_cast<const float4 *>(&dO_s[4 * li]);
@@ -496,6 +503,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     *reinterpret_cast<float4 *>(&partT[hw][4 * li]) = aT;
   }
   __syncthreads();
+  AT_STAMP(1, 7)       // per-key gradients stored, partial dQ / d(qt) in LDS
   if (tid < D) {
     float dQ = 0.f, dT = 0.f;
 #pragma unroll
@@ -507,6 +515,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
     p.d_qt_pre[(size_t)b * 2 * D + D + tid] = dT;
   }
   __syncthreads();
+  AT_STAMP(1, 8)       // dQ, d(qt) reduced
   // ---- d(dec_in)[c] = residual + [dQpre | dqt] . wqt[c, :]^T ; a wave per row, lanes along n
   {
     float dq[4];
@@ -538,6 +547,7 @@ __global__ __launch_bounds__(256) void ta_attn_decode_bwd_kernel(BwdArgs p) {
       }
     }
   }
+  AT_STAMP(1, 9)       // d(dec_in)
 }
 
 }  // namespace

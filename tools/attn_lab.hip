@@ -31,6 +31,18 @@ int main(int argc, char **argv) {
     (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
   }
   printf("B = %d: %.2f us per launch (stamped build, back to back)\n", B, ms * 1000.f / reps);
+  // backward of the same block (head layer_norm fused: d_pred in, d_out unused)
+  float *d_pred = dev_alloc<float>(B * D), *d_dec_in = dev_alloc<float>(B * D), *d_kv = dev_alloc<float>((size_t)R * 2 * D),
+        *d_x = dev_alloc<float>((size_t)R * D), *d_qt = dev_alloc<float>(B * 2 * D), *d_tp = dev_alloc<float>((size_t)B * 5 * L),
+        *d_ln = dev_alloc<float>(B * 2 * D), *d_head = dev_alloc<float>(B * 2 * D);
+  for (int round = 0; round < 2; ++round) {
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i)
+      if (mtam_ta_attn_decode_bwd(nullptr, dec_in, x, kv, 2 * D, 0, D, tq, tk, sl, wqt, tp, lg, save, B, L, H, 0, d_dec_in, d_kv, d_x, d_qt,
+                                  d_tp, d_ln, d_pred, hg, hsave, d_head, nullptr)) { printf("bwd: %s\n", mtam_last_error()); return 1; }
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  printf("backward: %.2f us per launch (stamped build, back to back)\n", ms * 1000.f / reps);
 #ifdef MTAM_ATTN_STAMPS
   unsigned long long st[2][16];
   (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_attn_stamps), sizeof(st));
@@ -38,6 +50,11 @@ int main(int argc, char **argv) {
                         "normalize, saves issued", "head layer_norm"};
   for (int i = 1; i < 9; ++i)
     if (st[0][i]) printf("  %-30s %6.2f us\n", pts[i], (double)(st[0][i] - st[0][0]) / 100.0);
+  const char *ptb[10] = {"start", "row loads issued", "head layer_norm backward", "normalize backward", "dW", "softmax backward", "gate backward",
+                         "per-key gradients", "dQ, d(qt) reduced", "d(dec_in)"};
+  printf("backward:\n");
+  for (int i = 1; i < 10; ++i)
+    if (st[1][i]) printf("  %-30s %6.2f us\n", ptb[i], (double)(st[1][i] - st[1][0]) / 100.0);
 #endif
   return 0;
 }
