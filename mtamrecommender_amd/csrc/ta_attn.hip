@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
   const float ln_g = (tid < D) ? p.ln_gamma[tid] : 0.f, ln_b = (tid < D) ? p.ln_beta[tid] : 0.f;
   const float tq = p.t_query[b];
   float4 kq[KB], xq[KB], vq[KB];
-  float tk[KB], tp[KB][5];
+  // the time-gate inputs of ONE key per lane: lane li of a half wave carries key li & 7 of the half wave's eight through
+  // the gate chain (tanh, log, tanh, sigmoid) -- with all 32 lanes repeating every key's chain that phase was 2.3 us
+  float tk_l, tp_l[5];
   auto load_keys = [&](int jb) {
 #pragma unroll
     for (int i = 0; i < KB; ++i) {
@@ -91,10 +93,11 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
       kq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.k_off + 4 * li]);
       vq[i] = *reinterpret_cast<const float4 *>(&p.kv[(row0 + jc) * p.ld_kv + p.v_off + 4 * li]);
       xq[i] = *reinterpret_cast<const float4 *>(&p.x[(row0 + jc) * D + 4 * li]);
-      tk[i] = p.t_keys[row0 + jc];
-#pragma unroll
-      for (int q = 0; q < 5; ++q) tp[i][q] = p.tparams[q * L + jc];
     }
+    const int jl = min(jb + 8 * (li & 7), L - 1);
+    tk_l = p.t_keys[row0 + jl];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) tp_l[q] = p.tparams[q * L + jl];
   };
   load_keys(hw);
   AT_STAMP(0, 1)       // argument-only loads issued
@@ -130,27 +133,46 @@ __global__ __launch_bounds__(256) void ta_attn_decode_fwd_kernel(FwdArgs p) {
   const float4 Q4 = *reinterpret_cast<const float4 *>(&Q_s[4 * li]);
   const float4 T4 = *reinterpret_cast<const float4 *>(&qt_s[4 * li]);
   auto score_keys = [&](int jb) {
+    // (1) both dot products of the half wave's eight keys, summed over the lanes (every lane ends with every sum)
+    float dKv[KB], dAv[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      dKv[i] = group_sum_fast(dot4(kq[i], Q4), lanes_per_head);
+      dAv[i] = group_sum_dpp<32>(dot4(xq[i], T4));
+    }
+    // (2) the gate chain, one key per lane
+    {
+      const int il = li & 7, jl = jb + 8 * il;
+      float dA = dAv[0];
+#pragma unroll
+      for (int i = 1; i < KB; ++i) dA = (il == i) ? dAv[i] : dA;
+      const float a = fast_tanh(dA);
+      const float delta = logf(fabsf(tq - tk_l) + 1.0f);
+      const float dk = fast_tanh(delta * tp_l[0] + tp_l[1]);
+      const float g = tp_l[2] * dk + tp_l[3] * a + tp_l[4];
+      const float sg = fast_sigmoid(g);
+      if (li < 8 && jl < L) {
+        const bool live = jl < sl;
+        a_s[jl] = live ? a : 0.f;
+        dk_s[jl] = live ? dk : 0.f;
+        sg_s[jl] = live ? sg : 0.f;
+      }
+    }
+    // (3) the scores: a head's first lane, with the key's gate back from LDS (written by a lane of this same wave)
 #pragma unroll
     for (int i = 0; i < KB; ++i) {
       const int j = jb + 8 * i;
       if (j >= L) break;
       if (j < sl) {
-        const float dK = group_sum_fast(dot4(kq[i], Q4), lanes_per_head);
-        const float dA = group_sum_dpp<32>(dot4(xq[i], T4));
-        const float a = fast_tanh(dA);
-        const float delta = logf(fabsf(tq - tk[i]) + 1.0f);
-        const float dk = fast_tanh(delta * tp[i][0] + tp[i][1]);
-        const float g = tp[i][2] * dk + tp[i][3] * a + tp[i][4];
-        const float sg = fast_sigmoid(g);
+        const float sg = sg_s[j];
         if ((li & (lanes_per_head - 1)) == 0) {
           const int h = li >> lph_shift;
-          qk_s[h][j] = dK;
-          sc_s[h][j] = (dK * sg) / inv_div;
+          qk_s[h][j] = dKv[i];
+          sc_s[h][j] = (dKv[i] * sg) / inv_div;
         }
-        if (li == 0) { a_s[j] = a; dk_s[j] = dk; sg_s[j] = sg; }
-      } else {
-        if (li < H) { qk_s[li][j] = 0.f; sc_s[li][j] = MASK_VALUE; }
-        if (li == 0) { a_s[j] = 0.f; dk_s[j] = 0.f; sg_s[j] = 0.f; }
+      } else if (li < H) {
+        qk_s[li][j] = 0.f;
+        sc_s[li][j] = MASK_VALUE;
       }
     }
   };
