@@ -496,8 +496,22 @@ def main():
     total = args.warmup + args.steps
     bt = p.batch(B_PER_GPU)
 
+    # Single GPU, Adam: the 32 staged feeds form a ring in HBM and the optimizer launch of every step copies the NEXT
+    # feed into the arena (Model/time_aware_path.py FeedRing, mtam_adam_images_clip_feed) -- a step is one graph launch
+    # with nothing in front of it.  MTAM_BENCH_FEED_RING=0 (and every data-parallel run, whose step is not one graph):
+    # a device -> device copy of the arena ahead of each step.
+    use_ring = (not use_dist and os.environ.get("MTAM_BENCH_FEED_RING", "1") != "0" and p.optimizer == "adam"
+                and p._clip_in_adam(p.nb_dense + p.nb_item + bt.n_slot))
+    ring = None
+    if use_ring:
+        ring = p.feed_ring(bt, n_batches)
+        for j, st in enumerate(staged):
+            ring.put(j, st)
+        ring.prime(0)
+
     def step(i):
-        bt.arena.copy_(staged[i % n_batches], non_blocking=True)      # device -> device, 128 KB
+        if ring is None:
+            bt.arena.copy_(staged[i % n_batches], non_blocking=True)      # device -> device, 128 KB
         model.step_train(bt)
 
     log("rank %d: model built, %d batches staged" % (rank, n_batches))
@@ -534,6 +548,10 @@ def main():
     loss_last = float(bt.loss[0].item())
     if not np.isfinite(loss_last):
         raise SystemExit("non-finite training loss")
+    if ring is not None:
+        if int(ring.cursor.item()) != total + 1:
+            raise SystemExit("feed ring: cursor %d after %d steps" % (int(ring.cursor.item()), total))
+        bt.feed_ring = None          # the legs below feed the arena themselves
 
     # ---- per-kernel roofline legs (rank 0): back-to-back launches between HIP events
     result = None
@@ -659,6 +677,11 @@ def main():
                                       cat.category_count, cat.user_count, L, NB, H, B_PER_GPU),
                        "global_batch": B_PER_GPU * world, "seq_len": L, "parallelism": "dp%d" % world,
                        "id_dist": args.id_dist, "optimizer": "adam", "hipgraph": bool(model.use_graph),
+                       "feed": ("ring of %d packed feeds resident in HBM; the optimizer launch of step k copies feed "
+                                "k + 1 into the arena (one graph launch per step, nothing in front of it)" % n_batches
+                                if ring is not None else
+                                "%d packed feeds resident in HBM; a device-to-device copy of the arena ahead of each "
+                                "step" % n_batches),
                        "dp_graph": getattr(model, "_dp_mode", None) if use_dist else None},
             "recall_at_20_train_batch_smoke": recall,
             "recall_note": "Recall@20 of TRAINING batch 0 after the timed steps on synthetic records: a smoke value "

@@ -707,6 +707,19 @@ int mtam_adam_clip_max_partials(void);
 int mtam_adam_images_clip(float *p, float *m, float *v, const float *g, size_t n, const float *norm_partials,
                           int n_partials, float clip_norm, float *scale_out, const float *hyper, size_t sparse_begin,
                           uint16_t *copy16, size_t copy_begin, const MtamWeightImages *w, int n_w, void *stream);
+/* mtam_adam_images_clip that also hands the NEXT step its feed (Model/base_model.py:150-164: the feed_dict of the
+ * next sess.run): feed_ring holds feed_slots packed feed arenas of feed_words int32 words each, already in HBM (a
+ * device-resident epoch, or slots a loader fills ahead of the step); ONE more workgroup of the launch copies slot
+ * (feed_cursor[0] % feed_slots) into feed_arena -- the arena every kernel of the step reads its ids, times and learning
+ * rate from -- and adds one to feed_cursor[0].  Nothing in the optimizer launch reads the arena, so the copy rides in
+ * the update's shadow instead of standing in front of the next step's first kernel.  Contract: the slot the cursor
+ * points at is complete before this launch starts; the caller primes the first step (slot -> arena, cursor = index of
+ * the slot after it).  feed_words a multiple of 4, ring and arena 16-byte aligned and disjoint. */
+int mtam_adam_images_clip_feed(float *p, float *m, float *v, const float *g, size_t n, const float *norm_partials,
+                               int n_partials, float clip_norm, float *scale_out, const float *hyper,
+                               size_t sparse_begin, uint16_t *copy16, size_t copy_begin, const MtamWeightImages *w,
+                               int n_w, const int32_t *feed_ring, int feed_slots, int feed_words, int32_t *feed_arena,
+                               unsigned int *feed_cursor, void *stream);
 
 /* The other choices of base_model.init_optimizer (Model/base_model.py:71-80):
  * kind 0 GradientDescentOptimizer, 1 AdadeltaOptimizer (rho 0.95, eps 1e-8; slot1 = accum,

@@ -293,7 +293,16 @@ class base_model(object):
             p.sharded.exchange_and_apply(bt)
             return
         if p.allreduce_fn is None:
-            self._run("train", bt, p.train_kernels)
+            ring = getattr(bt, "feed_ring", None)
+            if ring is None:
+                self._run("train", bt, p.train_kernels)
+                return
+            # the feed is already in the arena (prime(), then every step's optimizer launch brings the next one):
+            # nothing is copied in front of the graph
+            if not ring.primed:
+                raise RuntimeError("feed ring: prime() it before the first step")
+            self._run("train", bt, p.train_kernels, key_extra=("ring", id(ring)))
+            ring.consumed += 1
             return
         if self._dp_mode is None:
             self._dp_mode = "fused" if p.world_size == 1 else "split"

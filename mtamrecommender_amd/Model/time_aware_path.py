@@ -183,6 +183,42 @@ class _Batch(object):
         return (v.view(torch.float32) if dt == torch.float32 else v).view(*shape)
 
 
+class FeedRing(object):
+    """Packed feeds resident in HBM, consumed by the captured training step WITHOUT a copy in front of it.
+
+    ``slots`` [n, words] int32: n packed feed arenas (``arena_layout``: ids, times, learning rate) -- a whole epoch of
+    them (ml-1m's 6,040 training sequences are 48 arenas = 6 MB; a million sequences 1 GB of the 288), or a short
+    ring a loader keeps ahead of the step.  The optimizer launch of step k carries one more workgroup that copies
+    slot (cursor % n) into ``bt.arena`` -- the fixed address every kernel of the step reads -- and advances the
+    cursor (``mtam_adam_images_clip_feed``): the feed of step k + 1 arrives in the shadow of step k's update, and a
+    step is ONE graph launch with nothing in front of it (the reference hands every ``sess.run`` its feed_dict,
+    Model/base_model.py:150-164; a device-to-device copy of the arena ahead of the graph cost 4.9 us of a 226 us
+    step).  ``prime()`` puts the first slot into the arena by an ordinary copy; after it, ``consumed`` counts the
+    steps launched and slot ``(consumed + 1) % n`` must be complete before the NEXT step is launched."""
+
+    def __init__(self, bt, n_slots):
+        self.bt, self.n = bt, int(n_slots)
+        self.words = bt.arena.numel()
+        self.slots = torch.zeros((self.n, self.words), dtype=torch.int32, device=bt.arena.device)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=bt.arena.device)
+        self.consumed = 0
+        self.primed = False
+
+    def put(self, slot, arena):
+        """A packed arena (device or pinned host tensor of ``words`` int32) -> slot ``slot`` (stream-ordered)."""
+        self.slots[slot % self.n].copy_(arena, non_blocking=True)
+
+    def prime(self, first_slot=0):
+        """slot ``first_slot`` -> arena, cursor -> the slot after it: the next step consumes ``first_slot``."""
+        self.bt.arena.copy_(self.slots[first_slot % self.n])
+        self.cursor.fill_(first_slot + 1)
+        self.consumed = first_slot
+        self.primed = True
+
+    def args(self):
+        return (self.slots, self.bt.arena, self.cursor)
+
+
 class TimeAwarePath(object):
     """Owns parameters, optimizer state and the kernel sequence for MTAM."""
 
@@ -297,6 +333,16 @@ class TimeAwarePath(object):
 
     def seg(self, name, flat=None):
         return self.layout.view(self.params if flat is None else flat, name)
+
+    def feed_ring(self, bt, n_slots):
+        """Attach a ring of ``n_slots`` HBM-resident packed feeds to ``bt`` (see FeedRing); ``bt.feed_ring = None``
+        detaches it.  Single-GPU Adam steps only: with a gradient exchange between backward and update the step is
+        not one graph, and the other optimizers have no launch that could carry the copy."""
+        if self.optimizer != "adam" or self.allreduce_fn is not None or self.sharded is not None or \
+                self.sharded_scoring is not None:
+            raise RuntimeError("feed ring: single-GPU Adam training steps only")
+        bt.feed_ring = FeedRing(bt, n_slots)
+        return bt.feed_ring
 
     def batch(self, B):
         if B not in self._batches:
@@ -753,10 +799,14 @@ class TimeAwarePath(object):
                                       bt.l2_live.numel(), bt.ce, bt.B, self.reg, 1.0 / gb,
                                       None if self.loss_in_tail else bt.loss)
             bt.norm_rode = False
+            ring = getattr(bt, "feed_ring", None)
             ops.adam_images_clip(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, part, n, self.clip,
                                  self.scale, self.adam_state, self.n_dense, self.wimg_descs, copy16=self.item16,
-                                 copy_begin=self.tab_off["item"])
+                                 copy_begin=self.tab_off["item"], feed=ring.args() if ring is not None else None)
             return
+        if getattr(bt, "feed_ring", None) is not None:
+            raise RuntimeError("a feed ring needs the optimizer launch that forms the clip scale itself "
+                               "(Adam, <= %d norm partials)" % ops.adam_clip_max_partials())
         ops.sqnorm_clip_scale(self.flat_g, n_g, part, 0, n, self.clip, self.scale, bt.feed["lr"],
                               self.adam_state, self.ticket, bt.l2_live, bt.l2_live.numel(), bt.ce, bt.B,
                               self.reg, 1.0 / gb, None if self.loss_in_tail else bt.loss)

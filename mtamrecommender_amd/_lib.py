@@ -124,6 +124,8 @@ SIGNATURES = {
     "mtam_adam_images": (c_int, [P, P, P, P, c_size_t, P, P, c_size_t, P, c_size_t, P, c_int, P]),
     "mtam_adam_images_clip": (c_int, [P, P, P, P, c_size_t, P, c_int, c_float, P, P, c_size_t, P, c_size_t, P, c_int,
                                       P]),
+    "mtam_adam_images_clip_feed": (c_int, [P, P, P, P, c_size_t, P, c_int, c_float, P, P, c_size_t, P, c_size_t, P,
+                                           c_int, P, c_int, c_int, P, P, P]),
     "mtam_adam_clip_max_partials": (c_int, []),
     "mtam_sqnorm_state_loss": (c_int, [P, c_size_t, P, c_int, P, P, P, c_int, P, c_int, c_float, c_float, P, P]),
     "mtam_opt_update": (c_int, [c_int, P, P, P, P, c_size_t, P, P, c_size_t, c_size_t, P]),

@@ -319,6 +319,15 @@ struct AdamImages {
   int n_norm;
   float clip;
   float *scale_out;
+  // mtam_adam_images_clip_feed: non-NULL = ONE more workgroup at the very end of the grid hands the NEXT step its
+  // feed -- slot (cursor % feed_slots) of a ring of packed feed arenas already in HBM goes into the arena the step's
+  // kernels read, and the cursor advances.  Nothing in this launch reads the arena (the learning rate was folded into
+  // hyper[0] by the state advance of an earlier launch), so the 128 KB move in the shadow of the update instead of
+  // being a copy in front of the next step's first kernel (4.9 us of a 226 us step at ml-1m sizes).
+  const int32_t *feed_ring;
+  int32_t *feed_arena;
+  unsigned *feed_cursor;
+  unsigned feed_slots, feed_words;            // words per slot (= the slot pitch)
 };
 
 template <bool COPY, bool NT>
@@ -370,6 +379,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
     pp = pp - num / den;
   };
   auto step = [&](float &pp, float &mm, float &vv, float gg) { step_form(pp, mm, vv, gg, sparse_form); };
+  if (wi.feed_ring && blockIdx.x == gridDim.x - 1) {
+    // ---- feed role: the next step's packed feed, ring slot -> arena (16-byte pieces, 16 in flight per thread)
+    const unsigned c = *wi.feed_cursor;
+    const int32_t *src = wi.feed_ring + (size_t)(c % wi.feed_slots) * wi.feed_words;
+    typedef int feed_i4 __attribute__((ext_vector_type(4)));
+    const unsigned n4 = wi.feed_words / 4;
+    for (unsigned b0 = 0; b0 < n4; b0 += 256 * 16) {
+      feed_i4 q[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const unsigned i = min(b0 + u * 256 + threadIdx.x, n4 - 1);
+        q[u] = reinterpret_cast<const feed_i4 *>(src)[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const unsigned i = b0 + u * 256 + threadIdx.x;
+        if (i < n4) reinterpret_cast<feed_i4 *>(wi.feed_arena)[i] = q[u];
+      }
+    }
+    for (unsigned i = 4 * n4 + threadIdx.x; i < wi.feed_words; i += 256) wi.feed_arena[i] = src[i];
+    __syncthreads();                           // every thread has read the cursor
+    if (threadIdx.x == 0) *wi.feed_cursor = c + 1;
+    return;
+  }
   if (wi.n && blockIdx.x >= wi.n_linear) {
     // ---- image role (dense variables: the non-sparse update form): 4 rows x 4 columns of the matrix per thread
     typedef float adam_f4 __attribute__((ext_vector_type(4)));
@@ -703,10 +736,17 @@ extern "C" int mtam_sqnorm_state_loss(const float *g, size_t n, float *partials,
 // 21 KB of L2 reads per workgroup), not for the 312 k blocks of a 10 M-row table
 extern "C" int mtam_adam_clip_max_partials(void) { return 1 << 14; }
 
+struct FeedNext {
+  const int32_t *ring = nullptr;
+  int32_t *arena = nullptr;
+  unsigned *cursor = nullptr;
+  int slots = 0, words = 0;
+};
+
 static int adam_images_launch(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
                               const float *norm_partials, int n_norm, float clip, float *scale_out,
                               const float *hyper, size_t sparse_begin, uint16_t *copy16, size_t copy_begin,
-                              const MtamWeightImages *w, int n_w, void *stream);
+                              const MtamWeightImages *w, int n_w, void *stream, FeedNext feed = FeedNext());
 
 extern "C" int mtam_adam_images(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
                                 const float *hyper, size_t sparse_begin, uint16_t *copy16, size_t copy_begin,
@@ -728,10 +768,35 @@ extern "C" int mtam_adam_images_clip(float *p, float *m, float *v, const float *
                             sparse_begin, copy16, copy_begin, w, n_w, stream);
 }
 
+extern "C" int mtam_adam_images_clip_feed(float *p, float *m, float *v, const float *g, size_t n,
+                                          const float *norm_partials, int n_partials, float clip_norm,
+                                          float *scale_out, const float *hyper, size_t sparse_begin, uint16_t *copy16,
+                                          size_t copy_begin, const MtamWeightImages *w, int n_w,
+                                          const int32_t *feed_ring, int feed_slots, int feed_words, int32_t *feed_arena,
+                                          unsigned int *feed_cursor, void *stream) {
+  MTAM_CHECK_ARG(norm_partials && scale_out && clip_norm > 0.f && n_partials > 0 &&
+                     n_partials <= mtam_adam_clip_max_partials(),
+                 "adam_images_clip_feed: 1 .. %d partials, a positive clip norm and a 2-float scale_out",
+                 mtam_adam_clip_max_partials());
+  MTAM_CHECK_ARG(feed_ring && feed_arena && feed_cursor && feed_slots > 0 && feed_words > 0,
+                 "adam_images_clip_feed: ring, arena, cursor, slots > 0, words > 0");
+  MTAM_CHECK_ARG(mtam_aligned16(feed_ring) && mtam_aligned16(feed_arena) && feed_words % 4 == 0,
+                 "adam_images_clip_feed: ring and arena 16-byte aligned, the slot pitch a multiple of 4 words");
+  {
+    const char *r0 = reinterpret_cast<const char *>(feed_ring), *r1 = r0 + (size_t)feed_slots * feed_words * 4;
+    const char *a0 = reinterpret_cast<const char *>(feed_arena), *a1 = a0 + (size_t)feed_words * 4;
+    MTAM_CHECK_ARG(a1 <= r0 || r1 <= a0, "adam_images_clip_feed: the arena may not lie inside the ring");
+  }
+  FeedNext f;
+  f.ring = feed_ring; f.arena = feed_arena; f.cursor = feed_cursor; f.slots = feed_slots; f.words = feed_words;
+  return adam_images_launch(p, m, v, g, n, nullptr, norm_partials, n_partials, clip_norm, scale_out, hyper,
+                            sparse_begin, copy16, copy_begin, w, n_w, stream, f);
+}
+
 static int adam_images_launch(float *p, float *m, float *v, const float *g, size_t n, const float *scale,
                               const float *norm_partials, int n_norm, float clip, float *scale_out,
                               const float *hyper, size_t sparse_begin, uint16_t *copy16, size_t copy_begin,
-                              const MtamWeightImages *w, int n_w, void *stream) {
+                              const MtamWeightImages *w, int n_w, void *stream, FeedNext feed) {
   MTAM_CHECK_ARG(p && m && v && g && hyper && n > 0, "adam_images: bad arguments");
   MTAM_CHECK_ARG(mtam_aligned16(p) && mtam_aligned16(m) && mtam_aligned16(v) && mtam_aligned16(g) &&
                      (reinterpret_cast<uintptr_t>(copy16) & 7u) == 0,
@@ -764,7 +829,9 @@ static int adam_images_launch(float *p, float *m, float *v, const float *g, size
     wi.gru_which[j] = w[j].gru_which;
     wi.first_block[j + 1] = wi.first_block[j] + (unsigned)(((size_t)(w[j].K / 4) * (w[j].N / 4) + 255) / 256);
   }
-  dim3 grid(wi.n_linear + wi.first_block[n_w]);
+  wi.feed_ring = feed.ring; wi.feed_arena = feed.arena; wi.feed_cursor = feed.cursor;
+  wi.feed_slots = (unsigned)feed.slots; wi.feed_words = (unsigned)feed.words;
+  dim3 grid(wi.n_linear + wi.first_block[n_w] + (feed.ring ? 1u : 0u));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool nt = n * 4 >= adam_nt_min_bytes();
   const size_t cb = copy16 ? copy_begin : n;

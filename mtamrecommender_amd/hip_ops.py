@@ -502,10 +502,22 @@ def adam_clip_max_partials():
 
 
 def adam_images_clip(p, m, v, g, n, norm_partials, n_partials, clip_norm, scale_out, hyper, sparse_begin, descs,
-                     copy16=None, copy_begin=0):
+                     copy16=None, copy_begin=0, feed=None):
     """adam_images where every workgroup derives the clip scale from the norm's partials itself (no ticket launch
-    before it: sqnorm_state_loss writes the partials); scale_out <- (scale, norm).  ``descs``: None = no images."""
+    before it: sqnorm_state_loss writes the partials); scale_out <- (scale, norm).  ``descs``: None = no images.
+    ``feed`` = (ring [slots, words] int32, arena [words] int32, cursor [1] int32): one more workgroup copies ring slot
+    cursor % slots into the arena for the NEXT step and advances the cursor (mtam_adam_images_clip_feed)."""
     arr, n_w = descs if descs is not None else (None, 0)
+    if feed is not None:
+        ring, arena, cursor = feed
+        assert ring.dtype == torch.int32 and arena.dtype == torch.int32 and cursor.dtype == torch.int32
+        assert ring.dim() == 2 and ring.is_contiguous() and ring.shape[1] == arena.numel() and cursor.numel() == 1
+        _lib.check(_lib.load().mtam_adam_images_clip_feed(
+            _p(p), _p(m), _p(v), _p(g), n, _p(norm_partials), int(n_partials), float(clip_norm), _p(scale_out),
+            _p(hyper), int(sparse_begin), _pb(copy16) if copy16 is not None else None, int(copy_begin),
+            ctypes.cast(arr, ctypes.c_void_p) if arr is not None else None, n_w, _pi(ring), int(ring.shape[0]),
+            int(ring.shape[1]), _pi(arena), _pi(cursor), _stream()), "mtam_adam_images_clip_feed")
+        return
     _lib.check(_lib.load().mtam_adam_images_clip(_p(p), _p(m), _p(v), _p(g), n, _p(norm_partials), int(n_partials),
                                                  float(clip_norm), _p(scale_out), _p(hyper), int(sparse_begin),
                                                  _pb(copy16) if copy16 is not None else None, int(copy_begin),

@@ -1389,6 +1389,62 @@ def test_clip_inside_the_optimizer_launch_equals_the_ticket_pair(ops, n_extra, w
     assert float(a[1][3][0]) < 1.0 and float(a[0][3][0]) == 1.0      # step 1 is clipped, step 0 is not
 
 
+@pytest.mark.parametrize("words,slots,with_images", [(32768, 5, True), (4096 + 12, 3, False), (8, 1, False), (65536 + 4, 2, True)])
+def test_optimizer_launch_hands_over_the_next_feed(ops, words, slots, with_images):
+    """mtam_adam_images_clip_feed: the update itself is mtam_adam_images_clip's bit for bit, and one more workgroup
+    copies ring slot (cursor % slots) into the arena and advances the cursor -- seven launches in a row walk the ring
+    (wrap-around included), nothing outside the arena is written, the ring is left as it was.  An arena inside the
+    ring, a slot pitch that is not a multiple of 4 words or a missing cursor are refused."""
+    rng = np.random.default_rng(words + slots)
+    blk = ops.adam_block()
+    n_dense, n = 3 * blk, 4 * blk + 128 * 7
+    nb = ops.sqnorm_blocks(n_dense)
+    mats = [(256, 16, 128)] if with_images else []
+    p0 = rng.standard_normal(n).astype(np.float32)
+    m0, v0 = (rng.standard_normal(n) * 0.1).astype(np.float32), rng.uniform(0, 0.1, n).astype(np.float32)
+    ring_np = rng.integers(-2 ** 31, 2 ** 31 - 1, (slots, words), dtype=np.int64).astype(np.int32)
+
+    def run(feed):
+        p, m, v = dev(p0), dev(m0), dev(v0)
+        state = dev(np.array([1e-3, 0.9, 0.999, 1e-8, 0.9, 0.999, 0.0, 0.0], np.float32))
+        scale = torch.zeros(2, device="cuda")
+        imgs = [torch.full((3 * K * N,), 7.0, dtype=torch.bfloat16, device="cuda") for _, K, N in mats]
+        descs = ops.weight_image_descs([(b, K, N, im) for (b, K, N), im in zip(mats, imgs)]) if mats else None
+        ring = torch.from_numpy(ring_np).cuda()
+        guard = torch.full((words + 64,), 0x5a5a5a5a, dtype=torch.int32, device="cuda")
+        arena = guard[32:32 + words]
+        cursor = torch.tensor([3], dtype=torch.int32, device="cuda")
+        out = []
+        for step in range(7):
+            g = dev((np.random.default_rng(step).standard_normal(n) * 0.01).astype(np.float32))
+            part = dev(np.random.default_rng(step + 9).uniform(0, 1e-3, nb + 11).astype(np.float32))
+            ops.adam_images_clip(p, m, v, g, n, part, nb + 11, 5.0, scale, state, n_dense, descs,
+                                 feed=(ring, arena, cursor) if feed else None)
+            if feed:
+                assert int(cursor.item()) == 3 + step + 1
+                assert torch.equal(arena, ring[(3 + step) % slots]), step
+                assert bool((guard[:32] == 0x5a5a5a5a).all()) and bool((guard[32 + words:] == 0x5a5a5a5a).all())
+            out.append([t.clone() for t in (p, m, v, scale)] + [im.clone() for im in imgs])
+        if feed:
+            assert np.array_equal(ring.cpu().numpy(), ring_np)
+        return out
+
+    for x, y in zip(run(False), run(True)):
+        for s, t in zip(x, y):
+            assert torch.equal(s, t)
+    p, m, v, g = dev(p0), dev(m0), dev(v0), dev(p0)
+    state, scale = dev(np.array([1e-3, 0.9, 0.999, 1e-8, 0.9, 0.999, 0.0, 0.0], np.float32)), torch.zeros(2, device="cuda")
+    part = torch.ones(nb, device="cuda")
+    ring = torch.zeros((4, 64), dtype=torch.int32, device="cuda")
+    cursor = torch.zeros(1, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError):            # the arena is one of the ring's own slots
+        ops.adam_images_clip(p, m, v, g, n, part, nb, 5.0, scale, state, n_dense, None, feed=(ring, ring[1], cursor))
+    ring6 = torch.zeros((4, 66), dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError):            # slot pitch not a multiple of 4 words
+        ops.adam_images_clip(p, m, v, g, n, part, nb, 5.0, scale, state, n_dense, None,
+                             feed=(ring6, torch.zeros(66, dtype=torch.int32, device="cuda"), cursor))
+
+
 @pytest.mark.parametrize("x3", [False, True])
 @pytest.mark.parametrize("R,n_kv,n_x", [(6400, 256, 384), (100, 512, 384), (33, 0, 384), (777, 256, 640)])
 def test_seq_chain_fwd_matches_the_three_products(ops, R, n_kv, n_x, x3):

@@ -517,6 +517,46 @@ def test_feed_and_loss_copies_inside_the_graph(hip_lib, tmp_path, async_loss):
         assert np.abs(va[k] - vb[k]).max() <= 2e-4 * max(1.0, np.abs(va[k]).max()), k
 
 
+def test_feed_ring_steps_equal_steps_fed_by_copies(hip_lib, tmp_path):
+    """A training step fed from a ring of HBM-resident packed feeds (path.feed_ring: the optimizer launch of step k
+    copies slot k + 1 into the arena, nothing stands in front of the graph) against the same steps with the arena
+    copied in front of each: 11 steps over a ring of 4 slots with a learning rate per slot -- the same loss at every
+    step, the arena holding the NEXT slot after every step, the cursor in step with the host's count, ONE captured
+    graph, the same parameters afterwards.  Refused without prime(), with another optimizer and under data parallelism."""
+    B, L, n_slots, steps = 16, 20, 4, 11
+    model_a, FLAGS, records = build(tmp_path, n_slots * B, L, 1, 1)
+    model_b, _, _ = build(tmp_path, n_slots * B, L, 1, 1)
+    pa, pb = model_a.path, model_b.path
+    feeds = [model_a.embedding.make_feed_dic_new(records[i * B:(i + 1) * B]) for i in range(n_slots)]
+    staged = [pa.stage(f, 1e-3 * (1 + i)) for i, f in enumerate(feeds)]
+    bta, btb = pa.batch(B), pb.batch(B)
+    ring = pb.feed_ring(btb, n_slots)
+    with pytest.raises(RuntimeError):
+        model_b.step_train(btb)                       # not primed
+    for i, st in enumerate(staged):
+        ring.put(i, st.to(btb.arena.device))
+    ring.prime(0)
+    for k in range(steps):
+        bta.arena.copy_(staged[k % n_slots])
+        model_a.step_train(bta)
+        model_b.step_train(btb)
+        la, lb = float(bta.loss[0].item()), float(btb.loss[0].item())
+        assert abs(la - lb) <= 2e-5 * abs(la), (k, la, lb)
+        assert torch.equal(btb.arena, ring.slots[(k + 1) % n_slots]), k
+        assert int(ring.cursor.item()) == k + 2 and ring.consumed == k + 1
+    assert len([k_ for k_ in model_b._graphs if k_[0] == "train" and k_[-1] != "warm"]) == 1
+    va, vb = model_a.get_variables(), model_b.get_variables()
+    for k in va:
+        assert np.abs(va[k] - vb[k]).max() <= 2e-4 * max(1.0, np.abs(va[k]).max()), k
+    # detached again: the ordinary route, its own graph
+    btb.feed_ring = None
+    btb.arena.copy_(staged[0])
+    model_b.step_train(btb)
+    model_c, _, _ = build(tmp_path, B, L, 1, 1, optimizer="sgd")
+    with pytest.raises(RuntimeError):
+        model_c.path.feed_ring(model_c.path.batch(B), 2)
+
+
 @pytest.mark.parametrize("native", [True, False])
 def test_trainer_loop_runs_on_both_feeds(hip_lib, tmp_path, native):
     from mtamrecommender_amd.data.synthetic import SyntheticCatalog, make_records
