@@ -172,15 +172,21 @@ class BatchPacker(object):
                      else torch.zeros(lay.words, dtype=torch.int32)) for _ in range(self.n_buffers))
             return lay, offsets, self._pools[(B, consumer)]
 
-    def pack(self, recordset, index, lr=0.0, consumer=None):
+    def pack(self, recordset, index, lr=0.0, consumer=None, into=None):
         """``consumer``: name of the batch stream this batch belongs to (None = the packer's own default
-        pool).  Every stream rotates through its own 3 arenas."""
+        pool).  Every stream rotates through its own 3 arenas.  ``into``: a caller-owned int32 host tensor of the
+        layout's size instead of a pool arena (resident epochs: the rows of one staging buffer)."""
         index = np.ascontiguousarray(index, dtype=np.int64)
         B = len(index)
         lay, offsets, pool = self._layout(B, consumer)
-        with self._lock:
-            arena = pool[0]
-            pool.rotate(-1)
+        if into is not None:
+            if into.dtype != torch.int32 or into.numel() != lay.words or not into.is_contiguous() or into.is_cuda:
+                raise ValueError("pack(into=...): a contiguous int32 host tensor of %d words" % lay.words)
+            arena = into
+        else:
+            with self._lock:
+                arena = pool[0]
+                pool.rotate(-1)
         err = ctypes.create_string_buffer(ERR_LEN)
         rc = self._lib.mtam_pack_batch(recordset._h, _ptr(index), B, self.L, ctypes.byref(lay),
                                        ctypes.byref(self.rows), float(lr), ctypes.c_void_p(arena.data_ptr()), err,

@@ -61,6 +61,22 @@ class SummaryWriter(object):
         self.rows = []
 
 
+class ResidentBatch(object):
+    """Handle of one batch of a device-resident epoch (``base_model.load_resident_epoch``): slot ``k`` of the feed
+    ring, the learning rate baked into it and the batch's target items (a view of the pinned staging buffer)."""
+
+    def __init__(self, ring, k, B, lr, targets):
+        self.ring, self.k, self.B, self.lr, self._targets = ring, k, B, lr, targets
+
+    def __len__(self):
+        return self.B
+
+    def field(self, name):
+        if name != "target_item_id":
+            raise KeyError(name)
+        return self._targets.numpy()
+
+
 class base_model(object):
 
     def __init__(self, FLAGS, Embedding):
@@ -81,6 +97,7 @@ class base_model(object):
         self.use_graph = os.environ.get("MTAM_HIP_GRAPH", "1") != "0"
         self._dp_mode = os.environ.get("MTAM_DP_GRAPH")       # None: decided at the first data-parallel step
         self._graphs = {}
+        self._resident_stage = None  # pinned [batches, words] staging buffer of load_resident_epoch
         self._feed_refs = {}        # pinned feed arenas whose address a captured step reads (kept alive with the graphs)
         # async_loss: train() hands back the loss of the PREVIOUS step (with the global_step it belongs to; nothing
         # on the first call) instead of blocking on this step's -- the reference's sess.run blocks (:159-164), and
@@ -301,7 +318,7 @@ class base_model(object):
             # nothing is copied in front of the graph
             if not ring.primed:
                 raise RuntimeError("feed ring: prime() it before the first step")
-            self._run("train", bt, p.train_kernels, key_extra=("ring", id(ring)))
+            self._run("train", bt, p.ring_train_kernels, key_extra=("ring", ring.serial))
             ring.consumed += 1
             return
         if self._dp_mode is None:
@@ -326,6 +343,7 @@ class base_model(object):
         p = self.path
         if isinstance(batch_data, PackedBatch):
             bt = p.batch(batch_data.B)
+            self._arena_taken(bt)
             lr_off = bt.offsets["lr"][0]
             batch_data.arena[lr_off:lr_off + 1].view(torch.float32)[0] = \
                 float(np.float32(learning_rate)) if learning_rate is not None else 0.0
@@ -333,7 +351,78 @@ class base_model(object):
             return bt, batch_data.field("target_item_id")
         input_dic = self.embedding.make_feed_dic_new(batch_data=batch_data)
         self.embedding.validate_ids(input_dic)
+        self._arena_taken(p.batch(len(input_dic[self.embedding.target_item_id])))
         return p.load_feed(input_dic, learning_rate), input_dic[self.embedding.target_item_id]
+
+    @staticmethod
+    def _arena_taken(bt):
+        """Someone else's feed goes into ``bt.arena`` (an evaluation batch of the training batch's size, a step fed
+        the ordinary way): a feed ring attached to it must put its next slot back before its next step.  The steps
+        in between run WITHOUT the feed role -- they are not the ring's."""
+        ring = getattr(bt, "feed_ring", None)
+        if ring is not None:
+            ring.primed = False
+
+    def load_resident_epoch(self, recordset, index, batch_size, learning_rates, packer):
+        """Pack ``len(learning_rates)`` full batches of ``batch_size`` records (``index``: the epoch's record order)
+        into a ring of feed arenas in HBM -- one staging buffer, ONE host -> device copy -- and return the
+        ``ResidentBatch`` handles ``train()`` takes in order.  Step k's learning rate travels in its slot.  The
+        optimizer launch of every step hands the next one its feed (Model/time_aware_path.py FeedRing): no copy per
+        step (reference: a feed_dict per sess.run, :150-164).  Single-GPU Adam steps through the graph only."""
+        p = self.path
+        n, B = len(learning_rates), int(batch_size)
+        if not self.use_graph:
+            raise RuntimeError("resident epochs replay the captured step: use_graph is off")
+        if n < 1 or len(index) < n * B:
+            raise ValueError("resident epoch: %d batches of %d need %d records, got %d" % (n, B, n * B, len(index)))
+        bt = p.batch(B)
+        ring = getattr(bt, "feed_ring", None)
+        if ring is None or ring.n != n:
+            if ring is not None:             # graphs captured on the old ring's addresses go with it
+                torch.cuda.synchronize()
+                self._graphs = {k: g for k, g in self._graphs.items()
+                                if not (k[0] == "train_ring" and k[3] == ring.serial)}
+            ring = p.feed_ring(bt, n)
+        if self._resident_stage is None or tuple(self._resident_stage.shape) != (n, ring.words):
+            self._resident_stage = torch.zeros((n, ring.words), dtype=torch.int32).pin_memory()
+            self._resident_copied = torch.cuda.Event()
+        else:
+            self._resident_copied.synchronize()        # the previous epoch's copy has read the staging buffer
+        for k in range(n):
+            packer.pack(recordset, index[k * B:(k + 1) * B], lr=float(np.float32(learning_rates[k])),
+                        into=self._resident_stage[k])
+        # (stream-ordered behind the previous epoch's last step, whose optimizer launch still read the ring)
+        ring.slots.copy_(self._resident_stage, non_blocking=True)
+        self._resident_copied.record()
+        ring.primed = False
+        targets = self._resident_stage[:, bt.offsets["target_item_id"][0]:][:, :B]
+        return [ResidentBatch(ring, k, B, float(np.float32(learning_rates[k])), targets[k]) for k in range(n)]
+
+    def _train_resident(self, rb, learning_rate, global_step):
+        ring, p = rb.ring, self.path
+        bt = ring.bt
+        if bt.feed_ring is not ring:
+            raise RuntimeError("resident batch of a ring that is no longer attached")
+        if abs(float(np.float32(learning_rate)) - rb.lr) > 1e-12:
+            raise ValueError("resident batch %d was packed with learning rate %r, train() got %r"
+                             % (rb.k, rb.lr, learning_rate))
+        if not ring.primed:                  # first step of the epoch, or the arena was used by someone else since
+            ring.prime(rb.k)
+        elif ring.consumed != rb.k:
+            raise RuntimeError("resident batches are consumed in order: expected %d, got %d" % (ring.consumed, rb.k))
+        cur = self._loss_begin() if self.async_loss else -1
+        host = self._loss_ring[cur][0] if cur >= 0 else None
+
+        def fn(bt_):
+            p.ring_train_kernels(bt_)
+            if host is not None:
+                host.copy_(bt_.loss, non_blocking=True)
+
+        self._run("train_ring", bt, fn, key_extra=(ring.serial, cur))
+        ring.consumed += 1
+        if cur >= 0:
+            return (bt,) + self._loss_end(cur, global_step, learning_rate)
+        return bt, bt.loss.cpu().numpy(), global_step, learning_rate
 
     def train(self, sess, batch_data, learning_rate, add_summary=False, global_step=0, epoch=0):
         """One optimizer step on one batch -> (loss, summary) (reference :150-167).
@@ -341,7 +430,9 @@ class base_model(object):
         With ``async_loss`` the pair belongs to the PREVIOUS step (``summary["loss_step"]`` / ``self.loss_step`` say
         which ``global_step``); the first call returns ``(nan, {"loss_step": None})`` -- nothing has finished yet --
         and ``drain_loss()`` hands over the most recent step's once the loop ends (or before a checkpoint)."""
-        if self._feed_in_graph(batch_data):
+        if isinstance(batch_data, ResidentBatch):
+            bt, loss, step, lr = self._train_resident(batch_data, learning_rate, global_step)
+        elif self._feed_in_graph(batch_data):
             bt, loss, step, lr = self._train_feed_in_graph(batch_data, learning_rate, global_step)
         else:
             bt, _ = self._load(batch_data, learning_rate)
@@ -374,6 +465,7 @@ class base_model(object):
     def _train_feed_in_graph(self, batch_data, learning_rate, global_step):
         p = self.path
         bt = p.batch(batch_data.B)
+        self._arena_taken(bt)
         lr_off = bt.offsets["lr"][0]
         batch_data.arena[lr_off:lr_off + 1].view(torch.float32)[0] = float(np.float32(learning_rate))
         src = batch_data.arena

@@ -196,8 +196,12 @@ class FeedRing(object):
     step).  ``prime()`` puts the first slot into the arena by an ordinary copy; after it, ``consumed`` counts the
     steps launched and slot ``(consumed + 1) % n`` must be complete before the NEXT step is launched."""
 
+    _serials = 0
+
     def __init__(self, bt, n_slots):
         self.bt, self.n = bt, int(n_slots)
+        FeedRing._serials += 1
+        self.serial = FeedRing._serials        # key of the graphs captured on this ring's addresses (never re-used, unlike id())
         self.words = bt.arena.numel()
         self.slots = torch.zeros((self.n, self.words), dtype=torch.int32, device=bt.arena.device)
         self.cursor = torch.zeros(1, dtype=torch.int32, device=bt.arena.device)
@@ -799,12 +803,13 @@ class TimeAwarePath(object):
                                       bt.l2_live.numel(), bt.ce, bt.B, self.reg, 1.0 / gb,
                                       None if self.loss_in_tail else bt.loss)
             bt.norm_rode = False
-            ring = getattr(bt, "feed_ring", None)
+            # (only the ring's own steps carry the feed role: an ordinary step on the same batch object brings its feed itself)
+            ring = getattr(bt, "feed_ring", None) if getattr(bt, "ring_step", False) else None
             ops.adam_images_clip(self.flat_p, self.flat_m, self.flat_v, self.flat_g, self.n_total, part, n, self.clip,
                                  self.scale, self.adam_state, self.n_dense, self.wimg_descs, copy16=self.item16,
                                  copy_begin=self.tab_off["item"], feed=ring.args() if ring is not None else None)
             return
-        if getattr(bt, "feed_ring", None) is not None:
+        if getattr(bt, "ring_step", False):
             raise RuntimeError("a feed ring needs the optimizer launch that forms the clip scale itself "
                                "(Adam, <= %d norm partials)" % ops.adam_clip_max_partials())
         ops.sqnorm_clip_scale(self.flat_g, n_g, part, 0, n, self.clip, self.scale, bt.feed["lr"],
@@ -858,6 +863,14 @@ class TimeAwarePath(object):
 
     def backward_from_pred_kernels(self, bt):
         self.backward(bt, score=False)
+
+    def ring_train_kernels(self, bt):
+        """train_kernels of a step whose feed came from ``bt.feed_ring``: the optimizer launch hands over the next."""
+        bt.ring_step = True
+        try:
+            self.train_kernels(bt)
+        finally:
+            bt.ring_step = False
 
     def train_kernels(self, bt):
         """Everything between feed upload and loss read-back; capturable."""

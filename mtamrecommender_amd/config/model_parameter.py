@@ -145,6 +145,12 @@ class model_parameter(object):
         f.DEFINE_boolean('async_loss', True,
                          'Train_main_process: model.train() returns the loss one step late instead of waiting for the '
                          'step it has just launched (the logged averages cover the same steps, shifted by one)')
+        f.DEFINE_boolean('resident_epoch', False,
+                         'Train_main_process (native_input, one GPU, adam): pack every full batch of an epoch into HBM '
+                         'up front (a ring of feed arenas: 128 KB per batch of 128 x 50) and let the optimizer launch of '
+                         'step k hand step k + 1 its feed (Model/time_aware_path.py FeedRing): no host -> device copy '
+                         'per step.  The learning rate of every step is baked into its slot (the schedule is a function '
+                         'of the global step); a last partial batch takes the ordinary route')
         f.DEFINE_boolean('allow_pickle_parameters', False,
                          'load a parameters.pkl written by the reference (Prepare/prepare_data_base.py:99-101) when no '
                          'parameters.json sits next to it; unpickling executes what the file says, so opt in only for '

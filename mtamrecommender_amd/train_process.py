@@ -173,10 +173,39 @@ class Train_main_process(object):
             from .data_parallel import keep_global_batch, shard as cut
             return ((i, _GlobalBatch(cut(b, self.rank, self.world), len(b))) for i, b in batches
                     if keep_global_batch(len(b), self.world))
+        if self._resident_epoch_on():
+            return self._resident_batches()
         from .DataHandle.native_input import NativeDataInput
         random.shuffle(self._order)          # the same permutation random.shuffle(train_set) would apply
         return NativeDataInput(self._train_rs, self.FLAGS.train_batch_size, self._packer, index=self._order,
                                consumer="train", shard=shard)
+
+    def _resident_epoch_on(self):
+        """FLAGS.resident_epoch: the epoch's full batches live in HBM and no feed is copied per step
+        (base_model.load_resident_epoch) -- native feed, one GPU, Adam, captured steps."""
+        return (bool(getattr(self.FLAGS, "resident_epoch", False)) and self._native and self.world == 1 and
+                self.model.path.optimizer == "adam" and self.model.use_graph)
+
+    def _resident_batches(self):
+        """The same (step, batch) stream as NativeDataInput over the same shuffled order: every full batch as a
+        ResidentBatch (its learning rate -- a function of the global step, next_learning_rate -- baked into its slot),
+        then the last partial batch, if any, the ordinary way (the reference keeps it: DataInput, input.py:12-19)."""
+        B = int(self.FLAGS.train_batch_size)
+        random.shuffle(self._order)
+        n_full = len(self._order) // B
+        lrs, lr = [], self.FLAGS.learning_rate
+        for k in range(n_full):
+            lr = next_learning_rate(lr, self.FLAGS.learning_rate, self.FLAGS.decay_rate, self.global_step + k)
+            lrs.append(lr)
+        handles = []
+        if n_full:
+            handles = self.model.load_resident_epoch(self._train_rs, np.asarray(self._order[:n_full * B], np.int64), B,
+                                                     lrs, self._packer)
+        for k, h in enumerate(handles):
+            yield k + 1, h
+        tail = self._order[n_full * B:]
+        if tail:
+            yield n_full + 1, self._packer.pack(self._train_rs, tail, consumer="train")
 
     def _test_batches(self):
         if not self._native:

@@ -572,6 +572,55 @@ def test_trainer_loop_runs_on_both_feeds(hip_lib, tmp_path, native):
     assert t.global_step == 6
 
 
+@pytest.mark.parametrize("test_batch", [16, 32])
+def test_resident_epoch_trainer_equals_the_streamed_one(hip_lib, tmp_path, test_batch):
+    """FLAGS.resident_epoch: every full batch of an epoch packed into HBM up front, the optimizer launch of step k
+    handing step k + 1 its feed, against the same trainer fed batch by batch: two epochs of 6 full batches + a partial
+    one (200 records / 32), evaluation every 4 steps -- with a test batch of the TRAINING batch's size the evaluation
+    takes the ring's arena and the ring must put its slot back -- the same losses under the same steps, the same
+    learning rates, the same parameters afterwards (float-atomic rounding apart)."""
+    import random
+    from mtamrecommender_amd.data.synthetic import SyntheticCatalog, make_records
+    from mtamrecommender_amd.train_process import Train_main_process
+    cat = SyntheticCatalog(120, 9, 30, seed=2)
+    train, test = make_records(cat, 200, 20, seed=3), make_records(cat, 40, 20, seed=4)
+    runs = []
+    for resident in (False, True):
+        d = tmp_path / ("r%d" % resident)
+        d.mkdir()
+        argv = ["--length_of_user_history", "20", "--train_batch_size", "32", "--test_batch_size", str(test_batch),
+                "--max_epochs", "2", "--eval_freq", "4", "--checkpoint_path_dir", str(d), "--native_input", "true",
+                "--resident_epoch", "true" if resident else "false"]
+        t = Train_main_process("MTAMb1_movielen", argv, train_set=list(train), test_set=list(test),
+                               counts=dict(user_count=30, item_count=120, category_count=9))
+        logged = {}
+        random.seed(5)
+        t.build_model()
+        built = t.model
+        if runs:
+            built.set_variables(start)          # both trainers start from the same parameters
+        else:
+            start = built.get_variables()
+        t.build_model = lambda: None
+        built.train_writer.add_summary = lambda summary, step, _l=logged: _l.setdefault(step, dict(summary)) \
+            if "Training Loss" in summary else None
+        t.train()
+        assert t.global_step == 14 and t._resident_epoch_on() == resident
+        runs.append((logged, built.get_variables(), built))
+    (la, va, _), (lb, vb, mb) = runs
+    assert sorted(la) == sorted(lb) == list(range(14))
+    for step in la:
+        assert abs(la[step]["normalized Training Loss"] - lb[step]["normalized Training Loss"]) <= \
+            3e-5 * abs(la[step]["normalized Training Loss"]), step
+        assert la[step]["Learning_rate"] == lb[step]["Learning_rate"]
+    for k in va:
+        assert np.abs(va[k] - vb[k]).max() <= 3e-4 * max(1.0, np.abs(va[k]).max()), k
+    ring = mb.path.batch(32).feed_ring
+    assert ring is not None and ring.n == 6
+    keys = [k for k in mb._graphs if k[0] == "train_ring" and k[-1] != "warm"]
+    assert 1 <= len(keys) <= 3          # one captured graph per pinned loss slot, none per batch
+
+
 @pytest.mark.parametrize("model_name,NB", [("MTAM", 2), ("MTAM_via_T_GRU", 1), ("PISTRec", 2)])
 def test_dead_variables_get_no_gradient_and_no_update(hip_lib, tmp_path, model_name, NB):
     """The variables the reference declares and never reads (oracle/specs.py ``live=False``: 6 GRU vectors,
