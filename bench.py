@@ -268,24 +268,29 @@ def host_inclusive_resident_rate(model, emb, records, steps, torch):
     n = len(records) // B_PER_GPU
     order = np.arange(n * B_PER_GPU, dtype=np.int64)
     done, t0, epochs = 0, None, 0
+    nxt = model.prepare_resident_epoch(rs, order, B_PER_GPU, [1e-3] * n, packer)
     while done < steps + 2 * n:
         if epochs == 2:                         # two untimed epochs: ring allocated, graphs captured
             torch.cuda.synchronize()
             t0, done = time.perf_counter(), 2 * n
-        for h in model.load_resident_epoch(rs, order, B_PER_GPU, [1e-3] * n, packer):
+        handles = model.load_resident_epoch(prepared=nxt)
+        nxt = model.prepare_resident_epoch(rs, order, B_PER_GPU, [1e-3] * n, packer)    # the next epoch, on a thread
+        for h in handles:
             model.train(model.sess, h, 1e-3)
             done += 1
         epochs += 1
     model.last_loss()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    nxt.thread.join()
     timed = done - 2 * n
     model.async_loss = False
     model.path.batch(B_PER_GPU).feed_ring = None
     return {"value": B_PER_GPU * timed / elapsed, "unit": "sequences/s", "ms_per_step": elapsed / timed * 1e3,
             "steps": timed, "epochs": epochs - 2,
-            "route": "RecordSet -> native packer -> ONE pinned staging buffer and ONE H2D copy per epoch of %d batches "
-                     "(timed) -> model.train(ResidentBatch): one hipGraph launch per step, the optimizer launch hands "
+            "route": "RecordSet -> native packer (epoch e + 1 packed on a worker thread while epoch e trains) -> pinned "
+                     "staging buffer -> H2D copy of the epoch's %d batches on a side stream (timed) -> "
+                     "model.train(ResidentBatch): one hipGraph launch per step, the optimizer launch hands "
                      "the next step its feed; loss D2H copy as the graph's last node, returned one step late" % n}
 
 

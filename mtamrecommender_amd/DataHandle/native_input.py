@@ -154,6 +154,17 @@ class BatchPacker(object):
         A pool belongs to ONE consumer (one batch stream): the train stream's prefetched batch must not sit
         in a buffer that an evaluation pass of the same batch size rotates through (round-1 advice: a shared
         pool let the third test batch overwrite the pending train batch when the batch sizes were equal)."""
+        lay, offsets = self.layout_only(B)
+        with self._lock:
+            if (B, consumer) not in self._pools:
+                pin = torch.cuda.is_available()
+                self._pools[(B, consumer)] = deque(
+                    (torch.zeros(lay.words, dtype=torch.int32).pin_memory() if pin
+                     else torch.zeros(lay.words, dtype=torch.int32)) for _ in range(self.n_buffers))
+            return lay, offsets, self._pools[(B, consumer)]
+
+    def layout_only(self, B):
+        """(C layout struct, field offsets) of batch size B without touching any arena pool."""
         with self._lock:
             if B not in self._layouts:
                 from ..Model.time_aware_path import arena_layout
@@ -164,13 +175,7 @@ class BatchPacker(object):
                     setattr(lay, k, offsets[k][0])
                 lay.words = words
                 self._layouts[B] = (lay, offsets)
-            lay, offsets = self._layouts[B]
-            if (B, consumer) not in self._pools:
-                pin = torch.cuda.is_available()
-                self._pools[(B, consumer)] = deque(
-                    (torch.zeros(lay.words, dtype=torch.int32).pin_memory() if pin
-                     else torch.zeros(lay.words, dtype=torch.int32)) for _ in range(self.n_buffers))
-            return lay, offsets, self._pools[(B, consumer)]
+            return self._layouts[B]
 
     def pack(self, recordset, index, lr=0.0, consumer=None, into=None):
         """``consumer``: name of the batch stream this batch belongs to (None = the packer's own default
@@ -178,7 +183,10 @@ class BatchPacker(object):
         layout's size instead of a pool arena (resident epochs: the rows of one staging buffer)."""
         index = np.ascontiguousarray(index, dtype=np.int64)
         B = len(index)
-        lay, offsets, pool = self._layout(B, consumer)
+        if into is not None:         # no pool: nothing is allocated (a worker thread must not make HIP calls)
+            lay, offsets = self.layout_only(B)
+        else:
+            lay, offsets, pool = self._layout(B, consumer)
         if into is not None:
             if into.dtype != torch.int32 or into.numel() != lay.words or not into.is_contiguous() or into.is_cuda:
                 raise ValueError("pack(into=...): a contiguous int32 host tensor of %d words" % lay.words)

@@ -77,6 +77,14 @@ class ResidentBatch(object):
         return self._targets.numpy()
 
 
+class _ResidentPrep(object):
+    """An epoch being packed into pinned staging buffer ``j`` (base_model.prepare_resident_epoch)."""
+
+    def __init__(self, j, stage, n, B, lrs):
+        self.j, self.stage, self.n, self.B, self.lrs = j, stage, n, B, lrs
+        self.thread, self.error = None, None
+
+
 class base_model(object):
 
     def __init__(self, FLAGS, Embedding):
@@ -97,7 +105,9 @@ class base_model(object):
         self.use_graph = os.environ.get("MTAM_HIP_GRAPH", "1") != "0"
         self._dp_mode = os.environ.get("MTAM_DP_GRAPH")       # None: decided at the first data-parallel step
         self._graphs = {}
-        self._resident_stage = None  # pinned [batches, words] staging buffer of load_resident_epoch
+        # load_resident_epoch: two pinned [batches, words] staging buffers (+ the event behind the copy that last read
+        # each), used in turn; the side stream of the host -> device copies
+        self._resident_stages, self._resident_flip, self._resident_stream = [None, None], 0, None
         self._feed_refs = {}        # pinned feed arenas whose address a captured step reads (kept alive with the graphs)
         # async_loss: train() hands back the loss of the PREVIOUS step (with the global_step it belongs to; nothing
         # on the first call) instead of blocking on this step's -- the reference's sess.run blocks (:159-164), and
@@ -292,6 +302,10 @@ class base_model(object):
         the fused form has only been run with a one-rank group (this build's GPU box has one GPU), and a
         collective that misbehaves inside a replayed graph cannot be recovered from -- ``fused`` otherwise."""
         p = self.path
+        if getattr(bt, "feed_ring", None) is not None and (p.allreduce_fn is not None or p.sharded is not None or
+                                                           getattr(p, "sharded_scoring", None) is not None):
+            raise RuntimeError("a feed ring is attached to this batch but the step exchanges gradients between "
+                               "backward and update: detach it (bt.feed_ring = None)")
         if getattr(p, "sharded_scoring", None) is not None:
             # scoring row-sharded over the ranks: forward to pred (graph), the two scoring passes with their small
             # collectives (eager), backward from d_pred (graph), exchange + update (eager)
@@ -363,18 +377,61 @@ class base_model(object):
         if ring is not None:
             ring.primed = False
 
-    def load_resident_epoch(self, recordset, index, batch_size, learning_rates, packer):
-        """Pack ``len(learning_rates)`` full batches of ``batch_size`` records (``index``: the epoch's record order)
-        into a ring of feed arenas in HBM -- one staging buffer, ONE host -> device copy -- and return the
-        ``ResidentBatch`` handles ``train()`` takes in order.  Step k's learning rate travels in its slot.  The
-        optimizer launch of every step hands the next one its feed (Model/time_aware_path.py FeedRing): no copy per
-        step (reference: a feed_dict per sess.run, :150-164).  Single-GPU Adam steps through the graph only."""
+    RESIDENT_HEAD = 4         # slots copied (and waited for) before the epoch's first step; the rest lands behind it
+
+    def prepare_resident_epoch(self, recordset, index, batch_size, learning_rates, packer):
+        """Start packing an epoch (``len(learning_rates)`` full batches of ``batch_size`` records in the order
+        ``index``) into one of two pinned staging buffers ON A WORKER THREAD and return at once; hand the result to
+        ``load_resident_epoch(prepared=...)``.  A trainer calls this for epoch e + 1 right after loading epoch e, so
+        the packing (host only: libmtam_host.so, no HIP call on the worker) runs beside the steps of epoch e."""
+        import threading
         p = self.path
         n, B = len(learning_rates), int(batch_size)
-        if not self.use_graph:
-            raise RuntimeError("resident epochs replay the captured step: use_graph is off")
         if n < 1 or len(index) < n * B:
             raise ValueError("resident epoch: %d batches of %d need %d records, got %d" % (n, B, n * B, len(index)))
+        words = p.batch(B).arena.numel()
+        j = self._resident_flip
+        self._resident_flip ^= 1
+        slot = self._resident_stages[j]
+        if slot is None or tuple(slot[0].shape) != (n, words):        # (pinned memory: allocated on THIS thread)
+            slot = self._resident_stages[j] = [torch.zeros((n, words), dtype=torch.int32).pin_memory(), None]
+        elif slot[1] is not None:
+            slot[1].synchronize()             # the copy that last read this buffer (two epochs ago) is through
+        stage = slot[0]
+        index = np.array(index[:n * B], dtype=np.int64)               # the caller may reshuffle its list meanwhile
+        lrs = [float(np.float32(x)) for x in learning_rates]
+        packer.layout_only(B)                 # (what the worker needs of the packer, built on this thread)
+        prep = _ResidentPrep(j, stage, n, B, lrs)
+
+        def work():
+            try:
+                for k in range(n):
+                    packer.pack(recordset, index[k * B:(k + 1) * B], lr=lrs[k], into=stage[k])
+            except Exception as e:                    # re-raised by load_resident_epoch
+                prep.error = e
+
+        prep.thread = threading.Thread(target=work, daemon=True)
+        prep.thread.start()
+        return prep
+
+    def load_resident_epoch(self, recordset=None, index=None, batch_size=None, learning_rates=None, packer=None,
+                            prepared=None):
+        """Put an epoch's full batches (``len(learning_rates)`` of ``batch_size`` records, ``index`` = the epoch's
+        record order; or an epoch ``prepare_resident_epoch`` has packed meanwhile) into the ring of feed arenas in HBM
+        and return the ``ResidentBatch`` handles ``train()`` takes in order.  Step k's learning rate travels in its
+        slot.  The optimizer launch of every step hands the next one its feed (Model/time_aware_path.py FeedRing): no
+        copy per step (reference: a feed_dict per sess.run, :150-164).  The host -> device copy runs on a side stream
+        in two pieces -- the first RESIDENT_HEAD slots, which the first steps wait for, and the rest, which lands
+        behind them.  Single-GPU Adam steps through the graph only."""
+        p = self.path
+        if not self.use_graph:
+            raise RuntimeError("resident epochs replay the captured step: use_graph is off")
+        if prepared is None:
+            prepared = self.prepare_resident_epoch(recordset, index, batch_size, learning_rates, packer)
+        prepared.thread.join()
+        if prepared.error is not None:
+            raise prepared.error
+        n, B, stage = prepared.n, prepared.B, prepared.stage
         bt = p.batch(B)
         ring = getattr(bt, "feed_ring", None)
         if ring is None or ring.n != n:
@@ -383,20 +440,28 @@ class base_model(object):
                 self._graphs = {k: g for k, g in self._graphs.items()
                                 if not (k[0] == "train_ring" and k[3] == ring.serial)}
             ring = p.feed_ring(bt, n)
-        if self._resident_stage is None or tuple(self._resident_stage.shape) != (n, ring.words):
-            self._resident_stage = torch.zeros((n, ring.words), dtype=torch.int32).pin_memory()
-            self._resident_copied = torch.cuda.Event()
-        else:
-            self._resident_copied.synchronize()        # the previous epoch's copy has read the staging buffer
-        for k in range(n):
-            packer.pack(recordset, index[k * B:(k + 1) * B], lr=float(np.float32(learning_rates[k])),
-                        into=self._resident_stage[k])
-        # (stream-ordered behind the previous epoch's last step, whose optimizer launch still read the ring)
-        ring.slots.copy_(self._resident_stage, non_blocking=True)
-        self._resident_copied.record()
+        main = torch.cuda.current_stream()
+        if self._resident_stream is None:
+            self._resident_stream = torch.cuda.Stream()
+        side = self._resident_stream
+        # the previous epoch's last steps (queued on the main stream) still read the ring: the copy starts behind them
+        behind = torch.cuda.Event()
+        behind.record(main)
+        head = min(n, self.RESIDENT_HEAD)
+        ev_head, ev_rest = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(side):
+            side.wait_event(behind)
+            ring.slots[:head].copy_(stage[:head], non_blocking=True)
+            ev_head.record(side)
+            if n > head:
+                ring.slots[head:].copy_(stage[head:], non_blocking=True)
+            ev_rest.record(side)
+        self._resident_stages[prepared.j][1] = ev_rest
+        main.wait_event(ev_head)
+        ring.gate = (head, ev_rest) if n > head else None     # slots >= head: wait for ev_rest before the first use
         ring.primed = False
-        targets = self._resident_stage[:, bt.offsets["target_item_id"][0]:][:, :B]
-        return [ResidentBatch(ring, k, B, float(np.float32(learning_rates[k])), targets[k]) for k in range(n)]
+        targets = stage[:, bt.offsets["target_item_id"][0]:][:, :B]
+        return [ResidentBatch(ring, k, B, prepared.lrs[k], targets[k]) for k in range(n)]
 
     def _train_resident(self, rb, learning_rate, global_step):
         ring, p = rb.ring, self.path
@@ -406,6 +471,10 @@ class base_model(object):
         if abs(float(np.float32(learning_rate)) - rb.lr) > 1e-12:
             raise ValueError("resident batch %d was packed with learning rate %r, train() got %r"
                              % (rb.k, rb.lr, learning_rate))
+        gate = getattr(ring, "gate", None)
+        if gate is not None and rb.k + 1 >= gate[0]:          # this step's optimizer launch reads slot k + 1
+            torch.cuda.current_stream().wait_event(gate[1])
+            ring.gate = None
         if not ring.primed:                  # first step of the epoch, or the arena was used by someone else since
             ring.prime(rb.k)
         elif ring.consumed != rb.k:

@@ -186,26 +186,55 @@ class Train_main_process(object):
         return (bool(getattr(self.FLAGS, "resident_epoch", False)) and self._native and self.world == 1 and
                 self.model.path.optimizer == "adam" and self.model.use_graph)
 
-    def _resident_batches(self):
-        """The same (step, batch) stream as NativeDataInput over the same shuffled order: every full batch as a
-        ResidentBatch (its learning rate -- a function of the global step, next_learning_rate -- baked into its slot),
-        then the last partial batch, if any, the ordinary way (the reference keeps it: DataInput, input.py:12-19)."""
+    def _resident_plan(self, global_step0):
+        """Shuffle the order for one more epoch and describe it: (global step it starts at, record order of its full
+        batches, their learning rates -- next_learning_rate from FLAGS.learning_rate at the epoch's first step, as the
+        loop below computes them --, the records of the last partial batch)."""
         B = int(self.FLAGS.train_batch_size)
-        random.shuffle(self._order)
+        random.shuffle(self._order)          # the same permutation random.shuffle(train_set) would apply
         n_full = len(self._order) // B
         lrs, lr = [], self.FLAGS.learning_rate
         for k in range(n_full):
-            lr = next_learning_rate(lr, self.FLAGS.learning_rate, self.FLAGS.decay_rate, self.global_step + k)
+            lr = next_learning_rate(lr, self.FLAGS.learning_rate, self.FLAGS.decay_rate, global_step0 + k)
             lrs.append(lr)
-        handles = []
-        if n_full:
-            handles = self.model.load_resident_epoch(self._train_rs, np.asarray(self._order[:n_full * B], np.int64), B,
-                                                     lrs, self._packer)
+        return dict(step0=global_step0, index=np.asarray(self._order[:n_full * B], np.int64), lrs=lrs,
+                    tail=list(self._order[n_full * B:]), B=B, prepared=None)
+
+    def _resident_prepare(self, plan):
+        if plan["lrs"]:
+            plan["prepared"] = self.model.prepare_resident_epoch(self._train_rs, plan["index"], plan["B"], plan["lrs"],
+                                                                 self._packer)
+        return plan
+
+    def _resident_batches(self):
+        """The same (step, batch) stream as NativeDataInput over the same shuffled order: every full batch as a
+        ResidentBatch (its learning rate -- a function of the global step -- baked into its slot), then the last
+        partial batch, if any, the ordinary way (the reference keeps it: DataInput, input.py:12-19).  The NEXT
+        epoch is shuffled and packed on a worker thread as soon as this one is on the device."""
+        plan = getattr(self, "_resident_next", None)
+        self._resident_next = None
+        if plan is not None and plan["step0"] != self.global_step:
+            # (a swallowed step error moved the global step: the baked learning rates would be another step's.
+            # The order stays -- it is the epoch's shuffle -- the rates are recomputed.)
+            B, lrs, lr = plan["B"], [], self.FLAGS.learning_rate
+            for k in range(len(plan["lrs"])):
+                lr = next_learning_rate(lr, self.FLAGS.learning_rate, self.FLAGS.decay_rate, self.global_step + k)
+                lrs.append(lr)
+            if plan["prepared"] is not None:
+                plan["prepared"].thread.join()
+            plan.update(step0=self.global_step, lrs=lrs, prepared=None)
+        if plan is None:
+            plan = self._resident_plan(self.global_step)
+        if plan["prepared"] is None:
+            self._resident_prepare(plan)
+        handles = self.model.load_resident_epoch(prepared=plan["prepared"]) if plan["lrs"] else []
+        if self.now_epoch + 1 < self.FLAGS.max_epochs:
+            n_steps = len(plan["lrs"]) + (1 if plan["tail"] else 0)
+            self._resident_next = self._resident_prepare(self._resident_plan(self.global_step + n_steps))
         for k, h in enumerate(handles):
             yield k + 1, h
-        tail = self._order[n_full * B:]
-        if tail:
-            yield n_full + 1, self._packer.pack(self._train_rs, tail, consumer="train")
+        if plan["tail"]:
+            yield len(handles) + 1, self._packer.pack(self._train_rs, plan["tail"], consumer="train")
 
     def _test_batches(self):
         if not self._native:
