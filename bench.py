@@ -533,12 +533,12 @@ def main():
     total = args.warmup + args.steps
     bt = p.batch(B_PER_GPU)
 
-    # Single GPU, Adam: the 32 staged feeds form a ring in HBM and the optimizer launch of every step copies the NEXT
-    # feed into the arena (Model/time_aware_path.py FeedRing, mtam_adam_images_clip_feed) -- a step is one graph launch
-    # with nothing in front of it.  MTAM_BENCH_FEED_RING=0 (and every data-parallel run, whose step is not one graph):
-    # a device -> device copy of the arena ahead of each step.
-    use_ring = (not use_dist and os.environ.get("MTAM_BENCH_FEED_RING", "1") != "0" and p.optimizer == "adam"
-                and p._clip_in_adam(p.nb_dense + p.nb_item + bt.n_slot))
+    # Adam on one GPU or under the flat data-parallel exchange: the 32 staged feeds form a ring in HBM and the optimizer
+    # launch of every step copies the NEXT feed into the arena (Model/time_aware_path.py FeedRing,
+    # mtam_adam_images_clip_feed) -- on one GPU a step is one graph launch with nothing in front of it.
+    # MTAM_BENCH_FEED_RING=0 (and the row-sharded exchanges, which update through their own launches): a
+    # device -> device copy of the arena ahead of each step.
+    use_ring = os.environ.get("MTAM_BENCH_FEED_RING", "1") != "0" and p.ring_supported(bt)
     ring = None
     if use_ring:
         ring = p.feed_ring(bt, n_batches)
@@ -715,7 +715,9 @@ def main():
                        "global_batch": B_PER_GPU * world, "seq_len": L, "parallelism": "dp%d" % world,
                        "id_dist": args.id_dist, "optimizer": "adam", "hipgraph": bool(model.use_graph),
                        "feed": ("ring of %d packed feeds resident in HBM; the optimizer launch of step k copies feed "
-                                "k + 1 into the arena (one graph launch per step, nothing in front of it)" % n_batches
+                                "k + 1 into the arena (%s)"
+                                % (n_batches, "the update graph behind the all-reduce carries it" if use_dist else
+                                   "one graph launch per step, nothing in front of it")
                                 if ring is not None else
                                 "%d packed feeds resident in HBM; a device-to-device copy of the arena ahead of each "
                                 "step" % n_batches),
@@ -767,7 +769,7 @@ def main():
             result["host_inclusive"] = host_inclusive_rate(model, emb, records, min(args.steps, 300), torch)
             log("host-inclusive: %.0f sequences/s (%.3f ms per step)" % (result["host_inclusive"]["value"],
                                                                        result["host_inclusive"]["ms_per_step"]))
-            if use_ring:
+            if use_ring and not use_dist:
                 result["host_inclusive_resident_epoch"] = host_inclusive_resident_rate(model, emb, records,
                                                                                        min(args.steps, 300), torch)
                 log("host-inclusive, resident epochs: %.0f sequences/s (%.3f ms per step)"

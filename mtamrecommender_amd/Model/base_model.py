@@ -302,10 +302,12 @@ class base_model(object):
         the fused form has only been run with a one-rank group (this build's GPU box has one GPU), and a
         collective that misbehaves inside a replayed graph cannot be recovered from -- ``fused`` otherwise."""
         p = self.path
-        if getattr(bt, "feed_ring", None) is not None and (p.allreduce_fn is not None or p.sharded is not None or
-                                                           getattr(p, "sharded_scoring", None) is not None):
-            raise RuntimeError("a feed ring is attached to this batch but the step exchanges gradients between "
-                               "backward and update: detach it (bt.feed_ring = None)")
+        ring = getattr(bt, "feed_ring", None)
+        if ring is not None and (p.sharded is not None or getattr(p, "sharded_scoring", None) is not None):
+            raise RuntimeError("a feed ring is attached to this batch but the row-sharded exchanges update through "
+                               "their own launches: detach it (bt.feed_ring = None)")
+        if ring is not None and not ring.primed:
+            raise RuntimeError("feed ring: prime() it before the first step")
         if getattr(p, "sharded_scoring", None) is not None:
             # scoring row-sharded over the ranks: forward to pred (graph), the two scoring passes with their small
             # collectives (eager), backward from d_pred (graph), exchange + update (eager)
@@ -323,32 +325,33 @@ class base_model(object):
             self._run("train_fb", bt, p.forward_backward_kernels)
             p.sharded.exchange_and_apply(bt)
             return
+        # ring: the feed is already in the arena (prime(), then every step's optimizer launch brings the next one) --
+        # nothing is copied in front of the graph
+        rkey = ("ring", ring.serial) if ring is not None else ()
         if p.allreduce_fn is None:
-            ring = getattr(bt, "feed_ring", None)
-            if ring is None:
-                self._run("train", bt, p.train_kernels)
-                return
-            # the feed is already in the arena (prime(), then every step's optimizer launch brings the next one):
-            # nothing is copied in front of the graph
-            if not ring.primed:
-                raise RuntimeError("feed ring: prime() it before the first step")
-            self._run("train", bt, p.ring_train_kernels, key_extra=("ring", ring.serial))
-            ring.consumed += 1
+            self._run("train", bt, p.ring_train_kernels if ring is not None else p.train_kernels, key_extra=rkey)
+            if ring is not None:
+                ring.consumed += 1
             return
         if self._dp_mode is None:
             self._dp_mode = "fused" if p.world_size == 1 else "split"
         if self._dp_mode == "fused":
             try:
-                self._run("train_dp", bt, p.train_kernels, capture_error_mode="thread_local")
+                self._run("train_dp", bt, p.ring_train_kernels if ring is not None else p.train_kernels,
+                          key_extra=rkey, capture_error_mode="thread_local")
+                if ring is not None:
+                    ring.consumed += 1
                 return
             except Exception as e:                       # capture of the collective not supported here
                 self.logger.info("fused data-parallel graph unavailable (%s): using split graphs" % (e,))
                 self._dp_mode = "split"
-                self._graphs.pop(("train_dp", bt.B, getattr(p, "global_batch", None)), None)
+                self._graphs.pop(("train_dp", bt.B, getattr(p, "global_batch", None)) + rkey, None)
                 torch.cuda.synchronize()
         self._run("train_fb", bt, p.forward_backward_kernels)
         p.allreduce_fn(p, bt)
-        self._run("train_up", bt, p.clip_and_apply)
+        self._run("train_up", bt, p.ring_clip_and_apply if ring is not None else p.clip_and_apply, key_extra=rkey)
+        if ring is not None:
+            ring.consumed += 1
 
     def _load(self, batch_data, learning_rate=None):
         """Feed -> device arena.  A list of record tuples goes through make_feed_dic_new (the
@@ -426,6 +429,8 @@ class base_model(object):
         p = self.path
         if not self.use_graph:
             raise RuntimeError("resident epochs replay the captured step: use_graph is off")
+        if p.allreduce_fn is not None or p.sharded is not None or p.sharded_scoring is not None:
+            raise RuntimeError("resident epochs: single-GPU steps only (a data-parallel step is not one graph)")
         if prepared is None:
             prepared = self.prepare_resident_epoch(recordset, index, batch_size, learning_rates, packer)
         prepared.thread.join()

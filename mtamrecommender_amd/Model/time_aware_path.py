@@ -340,13 +340,23 @@ class TimeAwarePath(object):
 
     def feed_ring(self, bt, n_slots):
         """Attach a ring of ``n_slots`` HBM-resident packed feeds to ``bt`` (see FeedRing); ``bt.feed_ring = None``
-        detaches it.  Single-GPU Adam steps only: with a gradient exchange between backward and update the step is
-        not one graph, and the other optimizers have no launch that could carry the copy."""
-        if self.optimizer != "adam" or self.allreduce_fn is not None or self.sharded is not None or \
-                self.sharded_scoring is not None:
-            raise RuntimeError("feed ring: single-GPU Adam training steps only")
+        detaches it.  Adam steps on one GPU or under the flat data-parallel exchange (the optimizer launch behind the
+        all-reduce carries the copy just the same); the other optimizers have no launch that could carry it."""
+        if not self.ring_supported(bt):
+            raise RuntimeError("feed ring: Adam steps whose optimizer launch forms the clip scale itself (one GPU, or "
+                               "the flat data-parallel exchange); not the row-sharded exchanges, not the other "
+                               "optimizers")
         bt.feed_ring = FeedRing(bt, n_slots)
         return bt.feed_ring
+
+    def ring_supported(self, bt):
+        """Can this batch's optimizer launch carry the next step's feed (mtam_adam_images_clip_feed)?  It is the
+        launch clip_and_apply uses when the norm has few enough partials -- on one GPU and, under the flat
+        data-parallel exchange, behind the all-reduce.  The row-sharded exchanges update through their own launches."""
+        if self.optimizer != "adam" or self.sharded is not None or self.sharded_scoring is not None:
+            return False
+        n = self.nb_dense + self.nb_item + bt.n_slot if self.tf_compat else ops.sqnorm_blocks(self.n_total)
+        return self._clip_in_adam(n)
 
     def batch(self, B):
         if B not in self._batches:
@@ -869,6 +879,14 @@ class TimeAwarePath(object):
         bt.ring_step = True
         try:
             self.train_kernels(bt)
+        finally:
+            bt.ring_step = False
+
+    def ring_clip_and_apply(self, bt):
+        """clip_and_apply of a ring-fed step (the update half of a data-parallel step in two graphs)."""
+        bt.ring_step = True
+        try:
+            self.clip_and_apply(bt)
         finally:
             bt.ring_step = False
 

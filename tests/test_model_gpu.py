@@ -267,6 +267,56 @@ def test_data_parallel_code_path_single_rank(hip_lib, tmp_path, dp_mode):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("dp_mode", ["fused", "split"])
+def test_feed_ring_under_the_flat_exchange_single_rank(hip_lib, tmp_path, dp_mode):
+    """The flat data-parallel step (one-rank RCCL group, both graph forms) fed from the HBM ring -- the update graph
+    behind the all-reduce carries the hand-over of the next feed -- against the same step with the arena copied in
+    front of it: the same loss at each of 9 steps over a ring of 3, the arena holding the next slot after every step,
+    the same parameters afterwards.  The row-sharded exchanges refuse a ring."""
+    import torch.distributed as dist
+    from mtamrecommender_amd import data_parallel
+    os_env = __import__("os").environ
+    os_env.setdefault("MASTER_ADDR", "127.0.0.1")
+    os_env["MASTER_PORT"] = "29621" if dp_mode == "fused" else "29622"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        B, L, n_slots = 32, 50, 3
+        model_a, FLAGS, records = build(tmp_path, n_slots * B, L, 1, 1)
+        model_b, _, _ = build(tmp_path, n_slots * B, L, 1, 1)
+        for m in (model_a, model_b):
+            m._dp_mode = dp_mode
+            data_parallel.attach(m.path, 1, force=True, exchange="flat")
+            data_parallel.broadcast_parameters(m.path)
+        pa, pb = model_a.path, model_b.path
+        feeds = [model_a.embedding.make_feed_dic_new(records[i * B:(i + 1) * B]) for i in range(n_slots)]
+        staged = [pa.stage(f, 1e-3 * (1 + i)) for i, f in enumerate(feeds)]
+        bta, btb = pa.batch(B), pb.batch(B)
+        assert pb.ring_supported(btb)
+        ring = pb.feed_ring(btb, n_slots)
+        for i, st in enumerate(staged):
+            ring.put(i, st)
+        ring.prime(0)
+        for k in range(9):
+            bta.arena.copy_(staged[k % n_slots])
+            model_a.step_train(bta)
+            model_b.step_train(btb)
+            la, lb = float(bta.loss[0].item()), float(btb.loss[0].item())
+            assert abs(la - lb) <= 2e-5 * abs(la), (k, la, lb)
+            assert torch.equal(btb.arena, ring.slots[(k + 1) % n_slots]), k
+            assert int(ring.cursor.item()) == k + 2 and ring.consumed == k + 1
+        assert model_b._dp_mode == dp_mode
+        va, vb = model_a.get_variables(), model_b.get_variables()
+        for k in va:
+            assert np.abs(va[k] - vb[k]).max() <= 2e-4 * max(1.0, np.abs(va[k]).max()), k
+        model_c, _, _ = build(tmp_path, B, L, 1, 1)
+        data_parallel.attach(model_c.path, 1, force=True, exchange="sharded")
+        assert not model_c.path.ring_supported(model_c.path.batch(B))
+        with pytest.raises(RuntimeError):
+            model_c.path.feed_ring(model_c.path.batch(B), 2)
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("score_dtype", ["f32", "bf16"])
 def test_sharded_item_exchange_single_rank(hip_lib, tmp_path, score_dtype):
     """data_parallel.ShardedItemExchange (reduce-scatter by row range, shard-owned clip share and Adam, all-gather)
