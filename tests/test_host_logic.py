@@ -132,3 +132,47 @@ def test_embedding_feed_and_validation():
     bad["item_list"][0, 0] = 123
     with pytest.raises(IndexError):
         emb.validate_ids(bad)
+
+
+def test_feed_arena_layout_is_16_byte_granular():
+    """Every field of the packed feed arena starts on a 16-byte boundary and the arena is a whole number of 16-byte
+    pieces -- what the feed ring's hand-over (mtam_adam_images_clip_feed: feed_words % 4 == 0, 16-byte copies) and the
+    native packer rely on -- for ragged batch sizes and lengths too; the fields do not overlap."""
+    from mtamrecommender_amd.Model.time_aware_path import arena_layout
+    for B, L in [(1, 1), (3, 7), (16, 20), (33, 50), (128, 50), (127, 51), (2048, 200)]:
+        offsets, words = arena_layout(B, L)
+        assert words % 4 == 0
+        spans = sorted((o, o + n) for o, n, _, _ in offsets.values())
+        assert all(o % 4 == 0 for o, _ in spans)
+        assert all(a_end <= b_start for (_, a_end), (b_start, _) in zip(spans, spans[1:]))
+        assert spans[-1][1] <= words
+        assert offsets["lr"][1] == 4 and offsets["item_list"][1] == B * L
+
+
+def test_resident_epoch_plan_is_the_loops_schedule_and_order():
+    """FLAGS.resident_epoch bakes every step's learning rate into its feed slot ahead of time (Train_main_process.
+    _resident_plan): the list must be exactly what the per-step loop computes -- next_learning_rate restarts from
+    FLAGS.learning_rate at the epoch's first step and is a function of the running value and the global step
+    (the reference's train_process.py:330-337) -- across a decay boundary too; the full batches and the partial last
+    one partition the order random.shuffle produces, as DataInput cuts it."""
+    import random
+    import types
+    from mtamrecommender_amd.train_process import Train_main_process, next_learning_rate
+    for flags_lr, step0, n_rec, B in [(1e-3, 0, 200, 32), (5e-3, 95, 1000, 7), (1e-3, 1234, 64, 32)]:
+        me = types.SimpleNamespace(FLAGS=types.SimpleNamespace(train_batch_size=B, learning_rate=flags_lr, decay_rate=0.99),
+                                   _order=list(range(n_rec)))
+        random.seed(3)
+        plan = Train_main_process._resident_plan(me, step0)
+        random.seed(3)
+        want = list(range(n_rec))
+        random.shuffle(want)
+        n_full = n_rec // B
+        assert list(plan["index"]) == want[:n_full * B] and plan["tail"] == want[n_full * B:]
+        lr, loop = flags_lr, []
+        for k in range(n_full):                  # the loop of Train_main_process.train, step by step
+            lr = next_learning_rate(lr, flags_lr, 0.99, step0 + k)
+            loop.append(lr)
+        assert plan["lrs"] == loop and plan["step0"] == step0 and plan["B"] == B
+    assert len(set(loop)) == 1 and len(set(Train_main_process._resident_plan(
+        types.SimpleNamespace(FLAGS=types.SimpleNamespace(train_batch_size=1, learning_rate=1e-3, decay_rate=0.99),
+                              _order=list(range(250))), 0)["lrs"])) > 1      # the schedule moves inside a long epoch
