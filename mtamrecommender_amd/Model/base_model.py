@@ -307,7 +307,9 @@ class base_model(object):
             raise RuntimeError("a feed ring is attached to this batch but the row-sharded exchanges update through "
                                "their own launches: detach it (bt.feed_ring = None)")
         if ring is not None and not ring.primed:
-            raise RuntimeError("feed ring: prime() it before the first step")
+            if not ring.taken:
+                raise RuntimeError("feed ring: prime() it before the first step")
+            ring = None        # the caller has just put its own feed into the arena: an ordinary step, not the ring's
         if getattr(p, "sharded_scoring", None) is not None:
             # scoring row-sharded over the ranks: forward to pred (graph), the two scoring passes with their small
             # collectives (eager), backward from d_pred (graph), exchange + update (eager)
@@ -378,7 +380,7 @@ class base_model(object):
         in between run WITHOUT the feed role -- they are not the ring's."""
         ring = getattr(bt, "feed_ring", None)
         if ring is not None:
-            ring.primed = False
+            ring.primed, ring.taken = False, True
 
     RESIDENT_HEAD = 4         # slots copied (and waited for) before the epoch's first step; the rest lands behind it
 

@@ -207,6 +207,8 @@ class FeedRing(object):
         self.cursor = torch.zeros(1, dtype=torch.int32, device=bt.arena.device)
         self.consumed = 0
         self.primed = False
+        self.taken = False          # the arena was handed to someone else's feed since the last prime()
+        self.gate = None            # (first slot still in flight, event behind its copy): base_model.load_resident_epoch
 
     def put(self, slot, arena):
         """A packed arena (device or pinned host tensor of ``words`` int32) -> slot ``slot`` (stream-ordered)."""
@@ -217,7 +219,7 @@ class FeedRing(object):
         self.bt.arena.copy_(self.slots[first_slot % self.n])
         self.cursor.fill_(first_slot + 1)
         self.consumed = first_slot
-        self.primed = True
+        self.primed, self.taken = True, False
 
     def args(self):
         return (self.slots, self.bt.arena, self.cursor)

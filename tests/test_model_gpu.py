@@ -598,6 +598,14 @@ def test_feed_ring_steps_equal_steps_fed_by_copies(hip_lib, tmp_path):
     va, vb = model_a.get_variables(), model_b.get_variables()
     for k in va:
         assert np.abs(va[k] - vb[k]).max() <= 2e-4 * max(1.0, np.abs(va[k]).max()), k
+    # an ordinary step on the batch the ring is attached to (train() on a list of records puts its own feed into the
+    # arena): it runs without the hand-over, and the ring's next step puts its slot back
+    cursor = int(ring.cursor.item())
+    model_b.train(model_b.sess, records[:B], 1e-3)
+    assert not ring.primed and ring.taken and int(ring.cursor.item()) == cursor
+    ring.prime(2)
+    model_b.step_train(btb)
+    assert torch.equal(btb.arena, ring.slots[3 % n_slots]) and int(ring.cursor.item()) == 4
     # detached again: the ordinary route, its own graph
     btb.feed_ring = None
     btb.arena.copy_(staged[0])
