@@ -145,7 +145,10 @@ class model_parameter(object):
         f.DEFINE_boolean('async_loss', True,
                          'Train_main_process: model.train() returns the loss one step late instead of waiting for the '
                          'step it has just launched (the logged averages cover the same steps, shifted by one)')
-        f.DEFINE_boolean('resident_epoch', False,
+        f.DEFINE_integer('resident_epoch_max_bytes', 4 << 30,
+                         'resident_epoch only while an epoch of packed feeds (4 x (10 B L + 3 B + 4) bytes a batch: '
+                         '128 KB at 128 x 50) fits this many bytes of HBM; larger epochs are streamed batch by batch')
+        f.DEFINE_boolean('resident_epoch', True,
                          'Train_main_process (native_input, one GPU, adam): pack every full batch of an epoch into HBM '
                          'up front (a ring of feed arenas: 128 KB per batch of 128 x 50) and let the optimizer launch of '
                          'step k hand step k + 1 its feed (Model/time_aware_path.py FeedRing): no host -> device copy '

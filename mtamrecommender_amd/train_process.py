@@ -183,8 +183,18 @@ class Train_main_process(object):
     def _resident_epoch_on(self):
         """FLAGS.resident_epoch: the epoch's full batches live in HBM and no feed is copied per step
         (base_model.load_resident_epoch) -- native feed, one GPU, Adam, captured steps."""
-        return (bool(getattr(self.FLAGS, "resident_epoch", False)) and self._native and self.world == 1 and
-                self.model.path.optimizer == "adam" and self.model.use_graph)
+        if not (bool(getattr(self.FLAGS, "resident_epoch", False)) and self._native and self.world == 1 and
+                self.model.path.optimizer == "adam" and self.model.use_graph):
+            return False
+        from .Model.time_aware_path import arena_layout
+        B = int(self.FLAGS.train_batch_size)
+        n_full = len(self.train_set) // B
+        if n_full < 1:
+            return False
+        epoch_bytes = n_full * arena_layout(B, self.FLAGS.length_of_user_history)[1] * 4
+        if epoch_bytes > int(getattr(self.FLAGS, "resident_epoch_max_bytes", 4 << 30)):
+            return False
+        return self.model.path.ring_supported(self.model.path.batch(B))
 
     def _resident_plan(self, global_step0):
         """Shuffle the order for one more epoch and describe it: (global step it starts at, record order of its full
