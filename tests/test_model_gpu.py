@@ -567,15 +567,16 @@ def test_feed_and_loss_copies_inside_the_graph(hip_lib, tmp_path, async_loss):
         assert np.abs(va[k] - vb[k]).max() <= 2e-4 * max(1.0, np.abs(va[k]).max()), k
 
 
-def test_feed_ring_steps_equal_steps_fed_by_copies(hip_lib, tmp_path):
+@pytest.mark.parametrize("model_name", ["MTAM", "PISTRec", "MTAM_with_T_SeqRec"])
+def test_feed_ring_steps_equal_steps_fed_by_copies(hip_lib, tmp_path, model_name):
     """A training step fed from a ring of HBM-resident packed feeds (path.feed_ring: the optimizer launch of step k
     copies slot k + 1 into the arena, nothing stands in front of the graph) against the same steps with the arena
     copied in front of each: 11 steps over a ring of 4 slots with a learning rate per slot -- the same loss at every
     step, the arena holding the NEXT slot after every step, the cursor in step with the host's count, ONE captured
     graph, the same parameters afterwards.  Refused without prime(), with another optimizer and under data parallelism."""
     B, L, n_slots, steps = 16, 20, 4, 11
-    model_a, FLAGS, records = build(tmp_path, n_slots * B, L, 1, 1)
-    model_b, _, _ = build(tmp_path, n_slots * B, L, 1, 1)
+    model_a, FLAGS, records = build(tmp_path, n_slots * B, L, 1, 1, model_name=model_name)
+    model_b, _, _ = build(tmp_path, n_slots * B, L, 1, 1, model_name=model_name)
     pa, pb = model_a.path, model_b.path
     feeds = [model_a.embedding.make_feed_dic_new(records[i * B:(i + 1) * B]) for i in range(n_slots)]
     staged = [pa.stage(f, 1e-3 * (1 + i)) for i, f in enumerate(feeds)]
