@@ -482,10 +482,10 @@ class base_model(object):
         if gate is not None and rb.k + 1 >= gate[0]:          # this step's optimizer launch reads slot k + 1
             torch.cuda.current_stream().wait_event(gate[1])
             ring.gate = None
-        if not ring.primed:                  # first step of the epoch, or the arena was used by someone else since
+        if not ring.primed or ring.consumed != rb.k:
+            # first step of the epoch; or the arena was used by someone else since; or a handle out of order (a step
+            # that failed and was skipped, train_process's swallow_step_errors): the slot goes in by an ordinary copy
             ring.prime(rb.k)
-        elif ring.consumed != rb.k:
-            raise RuntimeError("resident batches are consumed in order: expected %d, got %d" % (ring.consumed, rb.k))
         cur = self._loss_begin() if self.async_loss else -1
         host = self._loss_ring[cur][0] if cur >= 0 else None
 

@@ -676,6 +676,13 @@ def test_resident_epoch_trainer_equals_the_streamed_one(hip_lib, tmp_path, test_
         assert np.abs(va[k] - vb[k]).max() <= 3e-4 * max(1.0, np.abs(va[k]).max()), k
     ring = mb.path.batch(32).feed_ring
     assert ring is not None and ring.n == 6
+    # handles out of order (a skipped step): the slot goes in by a copy, the hand-over carries on from there
+    handles = mb.load_resident_epoch(t._train_rs, np.arange(192, dtype=np.int64), 32, [1e-3] * 6, t._packer)
+    for k in (0, 1, 4, 5, 2):
+        mb.train(mb.sess, handles[k], 1e-3)
+        assert ring.consumed == k + 1 and int(ring.cursor.item()) == k + 2
+        assert torch.equal(ring.bt.arena, ring.slots[(k + 1) % 6])
+    mb.drain_loss()
     keys = [k for k in mb._graphs if k[0] == "train_ring" and k[-1] != "warm"]
     assert 1 <= len(keys) <= 3          # one captured graph per pinned loss slot, none per batch
 
